@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the reference-defined ResNet-50 training step (fp32, 224x224, batch 256 per GPU)
+on N MI355X, through the drop-in C-ABI (load_new_batch -> forward_pass -> host loss -> backwards_pass ->
+update_parameters: the loop of resnet.cu:3340-3402).  Synthetic seeded data resident in HBM, random-init
+weights.  One JSON line on rank 0, with a `roofline` object for the dominant kernel family (HIP events
+around every launch of it, on the launch stream) and a `cpu_baseline` object (the CPU oracle timed on
+this host on a bounded sample; the reference has no CPU path of its own).
+
+  python bench.py --gpus 1 --steps 10 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_PEAK_TFLOPS = 157.3  # gfx950 fp32: vector FMA rate == fp32 MFMA rate (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+FAMILIES = {0: "direct conv 3x3/7x7 fwd+dgrad (dconv_kernel, VALU)", 1: "direct conv wgrad (wgrad_kernel, VALU)",
+            2: "1x1 conv / FC GEMM (gemm_mfma_kernel, fp32 MFMA)", 3: "batch norm fwd+bwd"}
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """The oracle (a CPU port: the reference has no CPU path) on a bounded sample of the same workload:
+    reference-defined ResNet-50, 224x224, fwd + bwd + Adam, batch 2, OpenMP over independent outputs."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import synth
+    from oracle.oracle_py import Oracle, OracleNet
+    cores = min(os.cpu_count() or 1, 64)
+    o = Oracle("f32")
+    o.set_threads(cores)
+    dims, batch = synth.R50_DIMS, 2
+    net = OracleNet(o, dims, batch)
+    params = synth.make_params(dims)
+    for i, p in enumerate(params):
+        net.param(i)[:] = p
+    im, lab = synth.make_batch(dims, batch)
+    net.set_batch(im, lab)
+    t0 = time.time()
+    net.forward()
+    net.loss()
+    net.backward()
+    net.update()
+    dt = time.time() - t0
+    net.close()
+    return {"value": batch / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "1 full training step (fwd+loss+bwd+Adam) of the reference-defined ResNet-50 fp32 224x224 at batch %d, "
+                      "oracle/liboracle_f32.so with %d OpenMP threads, %.1f s" % (batch, cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE: 256)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="disable the per-kernel HIP-event timing")
+    ap.add_argument("--bucket-mb", type=int, default=32)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    from resnet_amd import Trainer, resnet_dims
+    from resnet_amd import binding as B
+    lib = B.load()
+    if lib.mi_device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback exists)")
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # rendezvous + barrier + max-reduce only (gloo); collectives are RCCL in C
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    dims = resnet_dims()
+    tr = Trainer(dims, args.batch, lr=1e-4, wd=0.0, b1=0.9, b2=0.999, eps=1e-7, seed=1236, device=local_rank)
+    # every rank draws its own slice of the global batch: distinct image/label streams per rank
+    tr.source_synthetic(1234 + 7919 * rank, 1235 + 7919 * rank, pool_batches=2)
+    if world > 1:
+        import torch
+        nbytes = lib.mi_dp_unique_id_bytes()
+        uid = (C.c_char * nbytes)()
+        if rank == 0 and lib.mi_dp_get_unique_id(uid, nbytes) != 0:
+            raise SystemExit(tr.error())
+        t = torch.frombuffer(bytearray(uid.raw), dtype=torch.uint8).clone()
+        dist.broadcast(t, src=0)
+        raw = bytes(t.numpy().tobytes())
+        if lib.mi_dp_init(tr.t, rank, world, raw, nbytes) != 0:
+            raise SystemExit("mi_dp_init: " + tr.error())
+        lib.mi_dp_set_bucket_bytes(tr.t, args.bucket_mb << 20)
+
+    def barrier():
+        lib.mi_device_synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    losses = []
+    for _ in range(args.warmup):
+        losses.append(tr.step()[0])
+    tr.check()
+    prof = not args.no_prof
+    if prof:
+        lib.mi_prof_enable(1)
+        lib.mi_prof_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses.append(tr.step()[0])
+    lib.mi_device_synchronize()
+    dt = time.perf_counter() - t0
+    barrier()
+    tr.check()
+    if dist is not None:
+        import torch
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+
+    fam_stats = {}
+    if prof:
+        for fam in FAMILIES:
+            n, ms, fl, by = C.c_long(0), C.c_double(0), C.c_double(0), C.c_double(0)
+            lib.mi_prof_get(fam, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by))
+            fam_stats[fam] = (n.value, ms.value, fl.value, by.value)
+        lib.mi_prof_enable(0)
+    timings = tr.timings()
+    tr.close()
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = args.batch * world * args.steps / dt
+        out = {"metric": "images/sec ResNet-50 fp32 224x224 batch256", "value": round(value, 2), "unit": "images/sec",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "reference-defined ResNet-50 (47.58M params, 3x3-s2 projections, Adam, sum loss), "
+                                      "fp32, 224x224, full training step, batch %d per GPU" % args.batch,
+                          "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                          "phase_ms_last_step": {"forward": round(timings[1], 3), "backward": round(timings[2], 3),
+                                                 "update": round(timings[3], 3)},
+                          "final_loss_per_image": round(losses[-1] / args.batch, 4)}}
+        if fam_stats:
+            dom = max(fam_stats, key=lambda f: fam_stats[f][1])
+            n, ms, fl, by = fam_stats[dom]
+            if dom == 3:
+                ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+                roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+            else:
+                ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+                roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": None}
+            roof["kernel"] = FAMILIES[dom]
+            roof["launches"] = n
+            roof["avg_launch_ms"] = round(ms / max(n, 1), 4)
+            roof["algorithmic_gflop_per_launch"] = round(fl / max(n, 1) / 1e9, 3)
+            roof["note"] = "fp32 peak 157.3 TFLOP/s is both the vector-FMA and the fp32-MFMA rate on gfx950"
+            roof["families_ms_per_step"] = {FAMILIES[f].split(" (")[0]: round(fam_stats[f][1] / args.steps, 3) for f in fam_stats}
+            roof["families_tflops"] = {FAMILIES[f].split(" (")[0]: round(fam_stats[f][2] / max(fam_stats[f][1], 1e-9) / 1e9, 2)
+                                       for f in fam_stats if fam_stats[f][2] > 0}
+            out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

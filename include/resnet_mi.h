@@ -1,0 +1,305 @@
+/*
+ * resnet_mi.h -- C-ABI of libresnet_mi.so: the MI355X (gfx950) drop-in for the trainer
+ * surface of als244/ResNet.
+ *
+ * The reference's headers declare only structs (resnet.h:4-215, resnet_cudnn.h:4-216); its
+ * entry points are C++ functions defined in resnet.cu.  This header keeps the struct layouts
+ * field-for-field in the reference's order (so code written against resnet.h keeps compiling and
+ * every offset is unchanged) and declares the entry points with C linkage, each citing the
+ * definition it replaces.  `bool` parameters became `int`; curandGenerator_t* became an opaque
+ * seed handle (MiRng*); the cudnnHandle_t member of resnet_cudnn.h:213 is the opaque
+ * `backend_ctx` slot (HIP streams, workspaces, RCCL communicator).
+ *
+ * Device memory layout: activations NCHW fp32 (north_star), weights KCRS as the reference
+ * (resnet.cu:140), FC weights [in][out] (resnet.cu:1751-1759).  All device pointers below are
+ * HIP device pointers owned by the trainer; nothing is freed before destroy_trainer().
+ */
+#ifndef RESNET_MI_H
+#define RESNET_MI_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------- reference struct layouts (resnet.h) ---------------- */
+typedef struct { /* resnet.h:4-9 */
+    char **labels;
+    char **synsets;
+    int *counts;
+    int n_classes;
+} Class_Metadata;
+
+typedef struct { /* resnet.h:11-33 */
+    int input;
+    int init_kernel_dim;
+    int init_conv_filters;
+    int init_conv_stride;
+    int init_maxpool_dim;
+    int init_maxpool_stride;
+    int n_conv_blocks;
+    int *is_block_spatial_reduction; /* caller-owned */
+    int final_depth;
+    int output;
+} Dims;
+
+typedef struct { /* resnet.h:35-40 */
+    int spatial_dim;
+    int depth;
+    float *gamma;
+    float *beta;
+} BatchNorm;
+
+typedef struct { /* resnet.h:43-74 */
+    int incoming_filters;
+    int incoming_spatial_dim;
+    int reduced_depth;
+    int expanded_depth;
+    int stride;
+    float *depth_reduction;
+    BatchNorm *norm_depth_reduction;
+    float *spatial;
+    BatchNorm *norm_spatial;
+    float *depth_expansion;
+    BatchNorm *norm_expansion;
+    float *projection; /* NULL when incoming_filters == expanded_depth */
+    BatchNorm *norm_projection;
+} ConvBlock;
+
+typedef struct { /* resnet.h:78-88 */
+    float *init_conv_layer;
+    BatchNorm *norm_init_conv;
+    ConvBlock **conv_blocks;
+    float *fully_connected;
+    float **locations; /* every tensor, order of resnet.cu:838-943 */
+    int *sizes;
+    int n_locations; /* COUNTED (3 + 9n + 3*#projections + 1), not the reference's 16+9n (:819) */
+} Params;
+
+typedef struct { /* resnet.h:90-97 */
+    int input_size;
+    int feature_size;
+    float *means;
+    float *vars;
+    float *normalized_temp; /* x-hat; NULL unless the trainer stores full activations */
+    float *normalized;      /* BN output before ReLU; NULL unless full-store */
+} Cache_BatchNorm;
+
+typedef struct { /* resnet.h:99-133 */
+    int incoming_filters;
+    int incoming_spatial_dim;
+    int reduced_depth;
+    int expanded_depth;
+    int stride;
+    float *post_reduced;
+    Cache_BatchNorm *norm_post_reduced;
+    float *post_reduced_activated;
+    float *post_spatial;
+    Cache_BatchNorm *norm_post_spatial;
+    float *post_spatial_activated;
+    float *post_expanded;
+    Cache_BatchNorm *norm_post_expanded;
+    float *post_expanded_norm_vals;
+    float *transformed_residual;
+    Cache_BatchNorm *norm_post_projection;
+    float *post_projection_norm_vals;
+    float *output;           /* pre-ReLU sum; aliases output_activated unless full-store */
+    float *output_activated;
+} Activation_ConvBlock;
+
+typedef struct { /* resnet.h:137-152 */
+    float *init_conv_applied;
+    Cache_BatchNorm *norm_init_conv;
+    float *init_conv_activated;
+    int *max_inds; /* flat NCHW argmax index */
+    float *init_convblock_input;
+    Activation_ConvBlock **activation_conv_blocks;
+    int n_conv_blocks;
+    float *final_conv_output_pooled;
+    float *linear_output;
+} Activations;
+
+typedef struct { /* resnet.h:154-157 */
+    Dims *dims;
+    Params *params;
+} ResNet;
+
+typedef struct { /* resnet.h:160-166 */
+    Activations *activations;
+    float *pred;
+    float *pred_cpu; /* valid when forward_pass returns */
+} Forward_Buffer;
+
+typedef struct { /* resnet.h:168-174 */
+    float *output_layer_deriv;
+    Params *param_derivs;
+    Params *prev_means;
+    Params *prev_vars;
+    Activations *activation_derivs;
+} Backprop_Buffer;
+
+typedef struct { /* resnet.h:176-192 */
+    int image_dim;
+    int image_size;
+    int n_images;
+    int cur_shard_id;
+    int cur_batch_in_shard;
+    int shard_n_images;
+    float *full_shard_images;
+    int *full_shard_correct_classes;
+    float *images_float_cpu; /* pinned */
+    float *images;           /* device, NCHW */
+    int *correct_classes_cpu; /* pinned; valid after load_new_batch */
+    int *correct_classes;
+} Batch;
+
+typedef struct { /* resnet.h:195-215, with resnet_cudnn.h:213's handle slot */
+    ResNet *model;
+    Batch *cur_batch;
+    Forward_Buffer *forward_buffer;
+    Backprop_Buffer *backprop_buffer;
+    float learning_rate;
+    float weight_decay;
+    float base_mean_decay;
+    float base_var_decay;
+    float cur_mean_decay;
+    float cur_var_decay;
+    float eps;
+    int batch_size;
+    int n_epochs;
+    int cur_dump_id;
+    int cur_epoch;
+    float *loss_per_epoch;
+    float *accuracy_per_epoch;
+    int init_loaded;
+    void *backend_ctx; /* resnet_cudnn.h:213 cudnnHandle_t -> opaque MiCtx* */
+    const char *dump_dir;
+} Train_ResNet;
+
+typedef struct MiRng MiRng; /* stands in for curandGenerator_t (resnet.cu:3264-3267) */
+
+/* ---------------- entry points the reference's main() calls ---------------- */
+/* resnet.cu:666 */
+Dims *init_dimensions(int input, int init_kernel_dim, int init_conv_filters, int init_conv_stride,
+                      int init_maxpool_dim, int init_maxpool_stride, int n_conv_blocks,
+                      int *is_block_spatial_reduction, int final_depth, int output);
+/* curandCreateGenerator + curandSetPseudoRandomGeneratorSeed, resnet.cu:3266-3267 */
+MiRng *mi_rng_create(uint64_t seed);
+void mi_rng_destroy(MiRng *);
+/* resnet.cu:951 (Glorot-normal var 2/(fan_in+fan_out), FC var 1e-4, gamma 1, beta 0) */
+ResNet *init_resnet(Dims *dims, MiRng *gen);
+/* resnet.cu:1196 */
+Batch *init_general_batch(int n_images, int image_size, int image_dim, int shard_n_images);
+/* resnet.cu:1157 */
+Train_ResNet *init_trainer(ResNet *model, Batch *cur_batch, int batch_size, float learning_rate, float weight_decay,
+                           float mean_decay, float var_decay, float eps, int n_epochs, const char *dump_dir);
+/* resnet_cudnn.cu:1160 (same, with the handle argument; `handle` is ignored) */
+Train_ResNet *init_trainer_cudnn_abi(ResNet *model, Batch *cur_batch, int batch_size, float learning_rate,
+                                     float weight_decay, float mean_decay, float var_decay, float eps, int n_epochs,
+                                     void *handle, const char *dump_dir);
+/* resnet.cu:1363 */
+Class_Metadata *populate_class_info(char *label_filename, char *synset_filename, char *class_size_filename,
+                                    int n_classes);
+/* resnet.cu:1235 */
+void load_new_batch(Train_ResNet *trainer, Class_Metadata *class_metadata, Batch *batch_buffer);
+/* resnet.cu:1526: fills forward_buffer->pred and pred_cpu (blocks until pred_cpu is valid) */
+void forward_pass(Train_ResNet *trainer);
+/* resnet.cu:1777: fills backprop_buffer->param_derivs */
+void backwards_pass(Train_ResNet *trainer);
+/* resnet.cu:2910: Adam, zero gradients + batch buffers, advance decays, dump every 1000 steps */
+void update_parameters(Train_ResNet *trainer);
+/* resnet.cu:2755 / 2778 / 2821 */
+void dump_trainer(int dump_id, Train_ResNet *trainer, const char *special_dir);
+void overwrite_trainer_hyperparams(Train_ResNet *trainer, int dump_id, const char *special_dir);
+void overwrite_model_params(Train_ResNet *trainer, int dump_id, const char *special_dir);
+
+/* ---------------- additions (new symbols; nothing above changes) ---------------- */
+int mi_device_count(void);
+int mi_set_device(int device);       /* call before any init_* ; default device 0 */
+const char *mi_last_error(void);     /* "" when no HIP/RCCL error has been recorded */
+void mi_device_synchronize(void);    /* cudaDeviceSynchronize of the reference main loop */
+void destroy_trainer(Train_ResNet *trainer); /* frees trainer, model, batch and every device buffer */
+
+/* data source selection for load_new_batch (the reference hard-codes /mnt/storage paths, :1275) */
+enum { MI_SRC_SHARDS = 0, MI_SRC_BUFFER = 1, MI_SRC_SYNTHETIC = 2, MI_SRC_HOST = 3 };
+enum { MI_LAYOUT_NHWC = 0, MI_LAYOUT_NCHW = 1 };
+/* shards: <dir>/%03d.images + %03d.labels (build_training_shards.c:150-160 / resnet.cu:1275-1285) */
+void mi_batch_source_shards(Batch *b, const char *shard_dir, int layout);
+/* one dumped batch: images.buffer / labels.buffer (resnet.cu:1301-1311) */
+void mi_batch_source_buffer(Batch *b, const char *images_path, const char *labels_path, int layout);
+/* seeded synthetic stream kept resident in HBM: images U(-124,152), labels uniform */
+void mi_batch_source_synthetic(Batch *b, uint64_t seed_images, uint64_t seed_labels, int n_classes, int pool_batches);
+/* caller fills images_float_cpu / correct_classes_cpu itself before each load_new_batch */
+void mi_batch_source_host(Batch *b, int layout);
+/* 0 = exit(1) on a missing shard/buffer file like fopen failure should (reference leaves it unchecked, :1276) */
+int mi_batch_last_status(const Batch *b);
+
+/* options (set after init_trainer, before the first forward_pass) */
+void mi_trainer_set_full_store(Train_ResNet *t, int on); /* also keep x-hat / BN-out / pre-ReLU sums (dump parity) */
+void mi_trainer_set_dump_root(Train_ResNet *t, const char *root); /* replaces /mnt/storage/.../training_dumps */
+void mi_trainer_set_dump_every(Train_ResNet *t, int every);       /* reference: 1000 (:2947); 0 disables */
+void mi_trainer_set_input_reset(Train_ResNet *t, int on);         /* reference zeroes images/labels each update (:2981) */
+float mi_host_loss(Train_ResNet *t, int *n_wrong);                /* resnet.cu:3363-3383 on pred_cpu */
+
+/* raw device access for tests / weight injection (model_params/%03d.buffer semantics, resnet.cu:2845-2874) */
+void mi_copy_to_device(void *dst_dev, const void *src_host, size_t bytes);
+void mi_copy_to_host(void *dst_host, const void *src_dev, size_t bytes);
+
+/* data parallel (new work): one process per GPU, RCCL all-reduce SUM of the gradient arena */
+int mi_dp_unique_id_bytes(void);
+int mi_dp_get_unique_id(void *out, int bytes);                        /* rank 0 */
+int mi_dp_init(Train_ResNet *t, int rank, int world, const void *unique_id, int bytes);
+void mi_dp_set_bucket_bytes(Train_ResNet *t, size_t bytes);
+int mi_dp_world(const Train_ResNet *t);
+
+/* per-phase device timing of the last step in ms: [0]=load [1]=forward [2]=backward [3]=update [4]=allreduce wait */
+void mi_trainer_last_timings(Train_ResNet *t, float out_ms[5]);
+
+/* optional per-kernel-family timing with HIP events on the launch stream (used by bench.py's roofline):
+ * family 0 direct conv fwd/dgrad (3x3, 7x7), 1 direct conv wgrad, 2 MFMA GEMM (1x1 conv, FC), 3 batch norm.
+ * flops/bytes are the ALGORITHMIC work of the timed launches. */
+void mi_prof_enable(int on);
+void mi_prof_reset(void);
+void mi_prof_get(int family, long *launches, double *ms, double *flops, double *bytes);
+
+/* ---------------- operator layer (prepareAndDo* of resnet.cu:1386-1509), device pointers, NCHW ----------------
+ * Exposed so parity tests can drive every kernel through the C-ABI on its own. `stream` NULL = the library's
+ * compute stream. All return 0 on success. */
+typedef void *mi_stream_t;
+void *mi_malloc(size_t bytes);
+void mi_free(void *p);
+int mi_op_conv_fwd(const float *x, const float *w_kcrs, float *y, int N, int C, int H, int K, int k, int stride);
+int mi_op_conv_dgrad(const float *w_kcrs, const float *dy, float *dx, int N, int C, int H, int K, int k, int stride,
+                     int to_add);
+int mi_op_conv_wgrad(const float *x, const float *dy, float *dw_kcrs, int N, int C, int H, int K, int k, int stride);
+int mi_op_bn_fwd(const float *x, const float *gamma, const float *beta, float *means, float *vars, float *y, int N,
+                 int C, int H, float eps, int relu);
+/* y = relu(BN(x) + residual) fused (addVec + doActivation, resnet.cu:1717-1723) */
+int mi_op_bn_fwd_add_relu(const float *x, const float *gamma, const float *beta, const float *residual, float *means,
+                          float *vars, float *y, int N, int C, int H, float eps);
+/* mask_mode 0 none, 1 own ReLU recomputed from x (activationAndBatchNormDeriv to_activate_deriv),
+ * 2 external: dy is gated by mask_src > 0 (doActivationDeriv fused in, resnet.cu:1934) */
+int mi_op_bn_bwd(const float *x, const float *gamma, const float *beta, const float *means, const float *vars,
+                 const float *dy, const float *mask_src, float *dx, float *dgamma, float *dbeta, int N, int C, int H,
+                 float eps, int mask_mode);
+int mi_op_maxpool_fwd(const float *x, float *y, int *max_inds, int N, int C, int H, int k, int stride);
+int mi_op_maxpool_bwd(const int *max_inds, const float *dy, float *dx, int N, int C, int H, int k, int stride);
+int mi_op_avgpool_fwd(const float *x, float *y, int N, int C, int H);
+int mi_op_avgpool_bwd(const float *dy, float *dx, int N, int C, int H);
+int mi_op_relu_deriv(const float *x, const float *up, float *out, size_t n);
+/* out[m x n] = A[m x k] * B[k x n], row-major (matMul, resnet.cu:70-85) and the two transposed forms
+ * (prepareAndDoMatMulLeftTranspose / RightTranspose, resnet.cu:1482-1509) */
+int mi_op_matmul(const float *A, const float *B, float *out, int m, int k, int n);
+int mi_op_matmul_lt(const float *A_kxm, const float *B, float *out, int m, int k, int n);
+int mi_op_matmul_rt(const float *A, const float *B_nxk, float *out, int m, int k, int n);
+int mi_op_softmax(const float *x, float *out, int N, int L);
+int mi_op_ce_deriv(const float *pred, const int *labels, float *d, int N, int L);
+int mi_op_adam(float *p, const float *g, float *m, float *v, size_t n, float lr, float wd, float b1, float b2,
+               float cur_b1, float cur_b2, float eps, int *nan_flag_dev);
+int mi_op_nhwc_to_nchw(const float *in, float *out, int N, int H, int W, int C);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,306 @@
+// kernels_bn.hip -- training-mode batch norm, forward and backward, NCHW (channel planes contiguous).
+// Replaces doBatchNormAndActivate / activationAndBatchNormDeriv (resnet.cu:289-426), which run one
+// thread per channel over N*H*W elements three times each.
+//
+// forward : (1) bn_stats   one HBM read of x: per-thread two-step (sum -> centred squares) on register
+//               batches, merged with Chan's parallel formula through wave shuffles, LDS and a per-channel
+//               partial table -- the result is the two-pass mean / biased variance of the reference,
+//               without its sequential-fp32 drift;
+//           (2) bn_apply   second read of x, one write: x_hat = (x-mean)/sqrt(var+eps), y = fma(gamma,
+//               x_hat, beta), optional ReLU, optional fused residual add + ReLU (addVec + doActivation,
+//               resnet.cu:1717-1723).  Algorithmic traffic 3 passes (2 reads + 1 write), +1 read if fused add.
+// backward: (1) bn_bwd_reduce  reads x, dy (+ mask source): s1 = sum g, s2 = sum g*x_hat (g = dy gated by
+//               ReLU');  (2) bn_bwd_apply  reads x, dy again, writes dx = gamma/sd * (g - s1/M - x_hat*s2/M),
+//               which is the reference's textbook dVar/dMean form (resnet.cu:394-422) with the exact-zero
+//               term sum(x-mean) dropped.  5 passes.
+#include "mi_common.hpp"
+#include "mi_device.h"
+
+#define BN_SPLIT_MAX 64
+
+struct Wel { float n, mean, m2; };
+__device__ __forceinline__ Wel wel_merge(Wel a, Wel b) {
+    Wel r;
+    r.n = a.n + b.n;
+    if (r.n == 0.f) { r.mean = 0.f; r.m2 = 0.f; return r; }
+    const float d = b.mean - a.mean, f = b.n / r.n;
+    r.mean = a.mean + d * f;
+    r.m2 = a.m2 + b.m2 + d * d * a.n * f;
+    return r;
+}
+__device__ __forceinline__ Wel wel_wave(Wel w) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Wel b;
+        b.n = __shfl_xor(w.n, o, 64); b.mean = __shfl_xor(w.mean, o, 64); b.m2 = __shfl_xor(w.m2, o, 64);
+        w = wel_merge(w, b);
+    }
+    return w;
+}
+__device__ __forceinline__ void wel_add4(Wel &w, float a, float b, float c, float d) {
+    const float bm = ((a + b) + (c + d)) * 0.25f;
+    const float da = a - bm, db = b - bm, dc = c - bm, dd = d - bm;
+    Wel t; t.n = 4.f; t.mean = bm; t.m2 = (da * da + db * db) + (dc * dc + dd * dd);
+    w = wel_merge(w, t);
+}
+__device__ __forceinline__ void wel_add1(Wel &w, float a) {
+    Wel t; t.n = 1.f; t.mean = a; t.m2 = 0.f;
+    w = wel_merge(w, t);
+}
+
+// grid (C, nsplit): block handles channel c, images n = split, split+nsplit, ...
+__global__ void __launch_bounds__(256)
+bn_stats_kernel(const float *__restrict__ x, float *__restrict__ partial, int N, int C, int P) {
+    const int c = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+    Wel w = {0.f, 0.f, 0.f};
+    if ((P & 3) == 0) {
+        const int P4 = P >> 2;
+        for (int n = split; n < N; n += nsplit) {
+            const float4 *src = (const float4 *)(x + ((size_t)n * C + c) * P);
+            for (int i = threadIdx.x; i < P4; i += blockDim.x) { const float4 v = src[i]; wel_add4(w, v.x, v.y, v.z, v.w); }
+        }
+    } else {
+        for (int n = split; n < N; n += nsplit) {
+            const float *src = x + ((size_t)n * C + c) * P;
+            for (int i = threadIdx.x; i < P; i += blockDim.x) wel_add1(w, src[i]);
+        }
+    }
+    w = wel_wave(w);
+    __shared__ Wel sh[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) sh[wv] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Wel r = sh[0];
+        for (int i = 1; i < (int)(blockDim.x >> 6); i++) r = wel_merge(r, sh[i]);
+        float *o = partial + ((size_t)c * BN_SPLIT_MAX + split) * 3;
+        o[0] = r.n; o[1] = r.mean; o[2] = r.m2;
+    }
+}
+
+// per-channel finalize: merges the split partials in fixed order; writes mean / biased var
+__global__ void bn_finalize_kernel(const float *__restrict__ partial, int nsplit, int C, float *__restrict__ means,
+                                   float *__restrict__ vars) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float *p = partial + (size_t)c * BN_SPLIT_MAX * 3;
+    Wel r = {p[0], p[1], p[2]};
+    for (int i = 1; i < nsplit; i++) { Wel b = {p[i * 3], p[i * 3 + 1], p[i * 3 + 2]}; r = wel_merge(r, b); }
+    means[c] = r.mean;
+    vars[c] = r.m2 / r.n;
+}
+
+// x_hat and y exactly as the reference writes them (resnet.cu:329-331); shared by forward and the backward
+// mask recomputation so the ReLU gate is bit-identical in both
+__device__ __forceinline__ float bn_xhat(float x, float mean, float sd) { return (x - mean) / sd; }
+__device__ __forceinline__ float bn_y(float xh, float g, float b) { return fmaf(g, xh, b); }
+
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+bn_apply_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
+                const float *__restrict__ means, const float *__restrict__ vars, const float *__restrict__ residual,
+                float *__restrict__ y, float *__restrict__ xhat_out, float *__restrict__ norm_out, int C, int P,
+                FastDiv fdP, FastDiv fdC, size_t total, float eps, int relu) {
+    constexpr int V = VEC ? 4 : 1;
+    const size_t nvec = total / V;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i * V;
+        const uint32_t plane = fd_div((uint32_t)e, fdP);
+        const uint32_t c = plane - fd_div(plane, fdC) * C;
+        const float mean = means[c], sd = sqrtf(vars[c] + eps), g = gamma[c], b = beta[c];
+        float v[V], r[V], xh[V], nv[V];
+        if (VEC) { const float4 t = *(const float4 *)(x + e); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+        else v[0] = x[e];
+        if (residual) {
+            if (VEC) { const float4 t = *(const float4 *)(residual + e); r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w; }
+            else r[0] = residual[e];
+        }
+#pragma unroll
+        for (int q = 0; q < V; q++) {
+            xh[q] = bn_xhat(v[q], mean, sd);
+            nv[q] = bn_y(xh[q], g, b);
+            float o = nv[q];
+            if (residual) o = fmaxf(o + r[q], 0.f);
+            else if (relu) o = fmaxf(o, 0.f);
+            v[q] = o;
+        }
+        if (VEC) {
+            *(float4 *)(y + e) = make_float4(v[0], v[1], v[2], v[3]);
+            if (xhat_out) *(float4 *)(xhat_out + e) = make_float4(xh[0], xh[1], xh[2], xh[3]);
+            if (norm_out) *(float4 *)(norm_out + e) = make_float4(nv[0], nv[1], nv[2], nv[3]);
+        } else {
+            y[e] = v[0];
+            if (xhat_out) xhat_out[e] = xh[0];
+            if (norm_out) norm_out[e] = nv[0];
+        }
+    }
+}
+
+// grid (C, nsplit): s1 = sum g, s2 = sum g * x_hat
+template <int MASK>
+__global__ void __launch_bounds__(256)
+bn_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ mask_src,
+                     const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ means,
+                     const float *__restrict__ vars, float *__restrict__ partial, int N, int C, int P, float eps) {
+    const int c = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+    const float mean = means[c], sd = sqrtf(vars[c] + eps), g = gamma[c], b = beta[c];
+    float s1 = 0.f, s2 = 0.f;
+    auto one = [&](float xv, float d, float m) {
+        const float xh = bn_xhat(xv, mean, sd);
+        bool on = true;
+        if (MASK == 1) on = bn_y(xh, g, b) > 0.f;
+        if (MASK == 2) on = m > 0.f;
+        if (on) { s1 += d; s2 = fmaf(d, xh, s2); }
+    };
+    if ((P & 3) == 0) {
+        const int P4 = P >> 2;
+        for (int n = split; n < N; n += nsplit) {
+            const size_t base = ((size_t)n * C + c) * P;
+            const float4 *xs = (const float4 *)(x + base), *ds = (const float4 *)(dy + base);
+            const float4 *ms = (const float4 *)(mask_src + (MASK == 2 ? base : 0));
+            for (int i = threadIdx.x; i < P4; i += blockDim.x) {
+                const float4 xv = xs[i], dv = ds[i];
+                float4 mv = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (MASK == 2) mv = ms[i];
+                one(xv.x, dv.x, mv.x); one(xv.y, dv.y, mv.y); one(xv.z, dv.z, mv.z); one(xv.w, dv.w, mv.w);
+            }
+        }
+    } else {
+        for (int n = split; n < N; n += nsplit) {
+            const size_t base = ((size_t)n * C + c) * P;
+            for (int i = threadIdx.x; i < P; i += blockDim.x)
+                one(x[base + i], dy[base + i], MASK == 2 ? mask_src[base + i] : 1.f);
+        }
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    __shared__ float sh[8];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { sh[wv * 2] = s1; sh[wv * 2 + 1] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, bsum = 0.f;
+        for (int i = 0; i < (int)(blockDim.x >> 6); i++) { a += sh[i * 2]; bsum += sh[i * 2 + 1]; }
+        float *o = partial + ((size_t)c * BN_SPLIT_MAX + split) * 3;
+        o[0] = a; o[1] = bsum;
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(float *__restrict__ partial, int nsplit, int C, float *__restrict__ dgamma,
+                                       float *__restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float *p = partial + (size_t)c * BN_SPLIT_MAX * 3;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < nsplit; i++) { s1 += p[i * 3]; s2 += p[i * 3 + 1]; }
+    dbeta[c] = s1;
+    dgamma[c] = s2;
+}
+
+template <int MASK, bool VEC>
+__global__ void __launch_bounds__(256)
+bn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ mask_src,
+                    const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ means,
+                    const float *__restrict__ vars, const float *__restrict__ dgamma, const float *__restrict__ dbeta,
+                    float *__restrict__ dx, int C, int P, FastDiv fdP, FastDiv fdC, size_t total, float inv_m, float eps) {
+    constexpr int V = VEC ? 4 : 1;
+    const size_t nvec = total / V;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i * V;
+        const uint32_t plane = fd_div((uint32_t)e, fdP);
+        const uint32_t c = plane - fd_div(plane, fdC) * C;
+        const float mean = means[c], sd = sqrtf(vars[c] + eps), g = gamma[c], b = beta[c];
+        const float k1 = dbeta[c] * inv_m, k2 = dgamma[c] * inv_m, scale = g / sd;
+        float xv[V], dv[V], mv[V];
+        if (VEC) {
+            const float4 t = *(const float4 *)(x + e); xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+            const float4 u = *(const float4 *)(dy + e); dv[0] = u.x; dv[1] = u.y; dv[2] = u.z; dv[3] = u.w;
+            if (MASK == 2) { const float4 m = *(const float4 *)(mask_src + e); mv[0] = m.x; mv[1] = m.y; mv[2] = m.z; mv[3] = m.w; }
+        } else {
+            xv[0] = x[e]; dv[0] = dy[e];
+            if (MASK == 2) mv[0] = mask_src[e];
+        }
+#pragma unroll
+        for (int q = 0; q < V; q++) {
+            const float xh = bn_xhat(xv[q], mean, sd);
+            bool on = true;
+            if (MASK == 1) on = bn_y(xh, g, b) > 0.f;
+            if (MASK == 2) on = mv[q] > 0.f;
+            const float gq = on ? dv[q] : 0.f;
+            xv[q] = scale * (gq - k1 - xh * k2);
+        }
+        if (VEC) *(float4 *)(dx + e) = make_float4(xv[0], xv[1], xv[2], xv[3]);
+        else dx[e] = xv[0];
+    }
+}
+
+static int bn_nsplit(int N, int C) {
+    int ns = mi_cdiv(2048, C);
+    if (ns > N) ns = N;
+    if (ns > BN_SPLIT_MAX) ns = BN_SPLIT_MAX;
+    if (ns < 1) ns = 1;
+    return ns;
+}
+static int ew_blocks(size_t nvec) {
+    size_t b = (nvec + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+extern "C" {
+size_t mid_bn_ws_floats(int C) { return (size_t)C * BN_SPLIT_MAX * 3; }
+
+int mid_bn_fwd(mid_stream s, float *ws, const float *x, const float *gamma, const float *beta, const float *residual,
+               float *means, float *vars, float *y, float *xhat_out, float *norm_out, int N, int C, int P, float eps,
+               int relu) {
+    hipStream_t st = (hipStream_t)s;
+    const int ns = bn_nsplit(N, C);
+    mi_prof_begin(st, MI_FAM_BN, 0.0, 4.0 * (double)N * C * P * (residual ? 4 : 3));
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, ns), dim3(256), 0, st, x, ws, N, C, P);
+    MI_LAUNCH_CHECK("bn_stats_kernel");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(mi_cdiv(C, 64)), dim3(64), 0, st, ws, ns, C, means, vars);
+    MI_LAUNCH_CHECK("bn_finalize_kernel");
+    const size_t total = (size_t)N * C * P;
+    const FastDiv fdP = make_fastdiv(P), fdC = make_fastdiv(C);
+    if ((P & 3) == 0)
+        hipLaunchKernelGGL((bn_apply_kernel<true>), dim3(ew_blocks(total / 4)), dim3(256), 0, st, x, gamma, beta, means,
+                           vars, residual, y, xhat_out, norm_out, C, P, fdP, fdC, total, eps, relu);
+    else
+        hipLaunchKernelGGL((bn_apply_kernel<false>), dim3(ew_blocks(total)), dim3(256), 0, st, x, gamma, beta, means,
+                           vars, residual, y, xhat_out, norm_out, C, P, fdP, fdC, total, eps, relu);
+    mi_prof_end(st);
+    MI_LAUNCH_CHECK("bn_apply_kernel");
+    return 0;
+}
+
+int mid_bn_bwd(mid_stream s, float *ws, const float *x, const float *gamma, const float *beta, const float *means,
+               const float *vars, const float *dy, const float *mask_src, float *dx, float *dgamma, float *dbeta, int N,
+               int C, int P, float eps, int mask_mode) {
+    hipStream_t st = (hipStream_t)s;
+    const int ns = bn_nsplit(N, C);
+    dim3 grid(C, ns), block(256);
+    if (mask_mode == 2 && !mask_src) { mi_record_error("mid_bn_bwd", "mask_src missing"); return -2; }
+    mi_prof_begin(st, MI_FAM_BN, 0.0, 4.0 * (double)N * C * P * (mask_mode == 2 ? 7 : 5));
+    if (mask_mode == 0) hipLaunchKernelGGL((bn_bwd_reduce_kernel<0>), grid, block, 0, st, x, dy, mask_src, gamma, beta, means, vars, ws, N, C, P, eps);
+    else if (mask_mode == 1) hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), grid, block, 0, st, x, dy, mask_src, gamma, beta, means, vars, ws, N, C, P, eps);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<2>), grid, block, 0, st, x, dy, mask_src, gamma, beta, means, vars, ws, N, C, P, eps);
+    MI_LAUNCH_CHECK("bn_bwd_reduce_kernel");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(mi_cdiv(C, 64)), dim3(64), 0, st, ws, ns, C, dgamma, dbeta);
+    MI_LAUNCH_CHECK("bn_bwd_finalize_kernel");
+    const size_t total = (size_t)N * C * P;
+    const FastDiv fdP = make_fastdiv(P), fdC = make_fastdiv(C);
+    const float inv_m = 1.0f / (float)((size_t)N * P);
+    const bool vec = (P & 3) == 0;
+    dim3 g2(ew_blocks(vec ? total / 4 : total));
+#define BWD_APPLY(M_, V_)                                                                                          \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<M_, V_>), g2, block, 0, st, x, dy, mask_src, gamma, beta, means, vars, \
+                       dgamma, dbeta, dx, C, P, fdP, fdC, total, inv_m, eps)
+    if (mask_mode == 0) { if (vec) BWD_APPLY(0, true); else BWD_APPLY(0, false); }
+    else if (mask_mode == 1) { if (vec) BWD_APPLY(1, true); else BWD_APPLY(1, false); }
+    else { if (vec) BWD_APPLY(2, true); else BWD_APPLY(2, false); }
+#undef BWD_APPLY
+    mi_prof_end(st);
+    MI_LAUNCH_CHECK("bn_bwd_apply_kernel");
+    return 0;
+}
+}

@@ -1,0 +1,260 @@
+// kernels_misc.hip -- the remaining HBM-bound kernels of the training step, NCHW:
+// max-pool (resnet.cu:433-494), global average pool (:500-542), ReLU' / add+ReLU (:59-65, :545-564),
+// soft-max + cross-entropy derivative (:569-602, stable form of resnet_cudnn.cu:572-583), fused Adam
+// (:605-662), layout conversion for NHWC shards/buffers, and the seeded synthetic batch generators.
+#include "mi_common.hpp"
+#include "mi_device.h"
+
+static int ew_blocks(size_t n, int per = 256) {
+    size_t b = (n + per - 1) / per;
+    if (b > 16384) b = 16384;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ---- max pool: window centred at stride*o, OOB skipped, strict '>' (first max wins), init -1024 ----
+__global__ void maxpool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int *__restrict__ idx, int NC,
+                                   int H, int Ho, int k, int stride) {
+    const size_t total = (size_t)NC * Ho * Ho;
+    const int half = k / 2;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const int ow = (int)(o % Ho);
+        const size_t t = o / Ho;
+        const int oh = (int)(t % Ho);
+        const size_t nc = t / Ho;
+        const float *xp = x + nc * H * H;
+        float mv = -1024.f;
+        int mi = -1024;
+        for (int r = -half; r <= half; r++) {
+            const int ih = stride * oh + r;
+            if (ih < 0 || ih >= H) continue;
+            for (int c = -half; c <= half; c++) {
+                const int iw = stride * ow + c;
+                if (iw < 0 || iw >= H) continue;
+                const float v = xp[ih * H + iw];
+                if (v > mv) { mv = v; mi = (int)(nc * H * H) + ih * H + iw; }
+            }
+        }
+        y[o] = mv;
+        idx[o] = mi;
+    }
+}
+// Backward in gather form: each input element looks at the windows that contain it, in the reference's
+// (oh, ow) scan order, and keeps the LAST one whose arg-max it is -- the deterministic execution of the
+// reference's racy plain-store scatter (resnet.cu:493; memset 0 at :2186).
+__global__ void maxpool_bwd_kernel(const int *__restrict__ idx, const float *__restrict__ dy, float *__restrict__ dx,
+                                   int NC, int H, int Ho, int k, int stride) {
+    const size_t total = (size_t)NC * H * H;
+    const int half = k / 2;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int iw = (int)(e % H);
+        const size_t t = e / H;
+        const int ih = (int)(t % H);
+        const size_t nc = t / H;
+        // outputs whose window covers (ih, iw): stride*oh - half <= ih <= stride*oh + half
+        int oh_lo = (ih - half + stride - 1) / stride; if (ih - half < 0) oh_lo = 0;
+        int oh_hi = (ih + half) / stride; if (oh_hi > Ho - 1) oh_hi = Ho - 1;
+        int ow_lo = (iw - half + stride - 1) / stride; if (iw - half < 0) ow_lo = 0;
+        int ow_hi = (iw + half) / stride; if (ow_hi > Ho - 1) ow_hi = Ho - 1;
+        float v = 0.f;
+        for (int oh = oh_lo; oh <= oh_hi; oh++)
+            for (int ow = ow_lo; ow <= ow_hi; ow++) {
+                const size_t o = (nc * Ho + oh) * Ho + ow;
+                if (idx[o] == (int)e) v = dy[o];
+            }
+        dx[e] = v;
+    }
+}
+
+// ---- global average pool: one wave per (n,c) plane ----
+__global__ void __launch_bounds__(256) avgpool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int NC, int P) {
+    const int lane = threadIdx.x & 63;
+    const int plane = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (plane >= NC) return;
+    const float *xp = x + (size_t)plane * P;
+    float s = 0.f;
+    for (int i = lane; i < P; i += 64) s += xp[i];
+    s = wave_sum(s);
+    if (lane == 0) y[plane] = s / (float)P;
+}
+__global__ void avgpool_bwd_kernel(const float *__restrict__ dy, float *__restrict__ dx, size_t total, int P) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x)
+        dx[e] = dy[e / P] / (float)P;
+}
+
+// ---- elementwise ----
+__global__ void relu_deriv_kernel(const float *__restrict__ x, const float *__restrict__ up, float *__restrict__ out, size_t n) {
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 a = ((const float4 *)x)[i], u = ((const float4 *)up)[i];
+        ((float4 *)out)[i] = make_float4(a.x > 0.f ? u.x : 0.f, a.y > 0.f ? u.y : 0.f, a.z > 0.f ? u.z : 0.f, a.w > 0.f ? u.w : 0.f);
+    }
+    for (size_t i = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = x[i] > 0.f ? up[i] : 0.f;
+}
+__global__ void add_relu_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ sum_out,
+                                float *__restrict__ act_out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float s = a[i] + b[i];
+        if (sum_out) sum_out[i] = s;
+        act_out[i] = fmaxf(0.f, s);
+    }
+}
+
+// ---- soft-max (one wave per row) and cross-entropy derivative (no 1/N: resnet.cu:1806-1811) ----
+__global__ void __launch_bounds__(64) softmax_kernel(const float *__restrict__ x, float *__restrict__ out, int L) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    const float *xr = x + (size_t)row * L;
+    float mx = -INFINITY;
+    for (int j = lane; j < L; j += 64) mx = fmaxf(mx, xr[j]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int j = lane; j < L; j += 64) s += expf(xr[j] - mx);
+    s = wave_sum(s);
+    for (int j = lane; j < L; j += 64) out[(size_t)row * L + j] = expf(xr[j] - mx) / s;
+}
+__global__ void ce_deriv_kernel(const float *__restrict__ pred, const int *__restrict__ labels, float *__restrict__ d, int N, int L) {
+    const size_t total = (size_t)N * L;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / L), col = (int)(i % L);
+        d[i] = pred[i] - (labels[row] == col ? 1.f : 0.f);
+    }
+}
+
+// ---- Adam, the three reference kernels fused; same guards (NaN/Inf gradient keeps m,v; NaN/Inf result keeps p) ----
+__global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+                            size_t n, float lr, float wd, float b1, float b2, float cur_b1, float cur_b2, float eps,
+                            int *__restrict__ nan_flag) {
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i], old = p[i];
+        float mi = m[i], vi = v[i];
+        if (isnan(gi) || isinf(gi)) bad = true;
+        else {
+            const float gd = gi + wd * old;
+            mi = b1 * mi + (1.f - b1) * gd;
+            vi = b2 * vi + (1.f - b2) * gd * gd;
+            m[i] = mi; v[i] = vi;
+        }
+        const float ma = mi / (1.f - cur_b1), va = vi / (1.f - cur_b2);
+        float np = old - (lr * (ma / (sqrtf(va) + eps)) + wd * old);
+        if (isnan(np) || isinf(np)) { np = old; bad = true; }
+        if (isnan(mi) || isinf(mi) || isnan(vi) || isinf(vi)) bad = true;
+        p[i] = np;
+    }
+    if (bad && nan_flag) atomicOr(nan_flag, 1);
+}
+
+// ---- layout ----
+__global__ void nhwc_to_nchw_kernel(const float *__restrict__ in, float *__restrict__ out, int N, int HW, int C) {
+    const size_t total = (size_t)N * HW * C;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const int p = (int)(o % HW);
+        const size_t t = o / HW;
+        const int c = (int)(t % C);
+        const size_t n = t / C;
+        out[o] = in[(n * HW + p) * C + c];
+    }
+}
+__global__ void nchw_to_nhwc_kernel(const float *__restrict__ in, float *__restrict__ out, int N, int C, int HW) {
+    const size_t total = (size_t)N * HW * C;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(o % C);
+        const size_t t = o / C;
+        const int p = (int)(t % HW);
+        const size_t n = t / HW;
+        out[o] = in[(n * C + c) * HW + p];
+    }
+}
+
+// ---- splitmix64 counter streams (same definition as tests/synth.py and csrc/synth.c) ----
+__device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t i) {
+    uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void fill_uniform_kernel(float *__restrict__ out, size_t n, uint64_t seed, uint64_t offset, float lo, float hi) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double u = (double)(splitmix64_at(seed, offset + i) >> 11) * (1.0 / 9007199254740992.0);
+        out[i] = (float)((double)lo + ((double)hi - (double)lo) * u);
+    }
+}
+__global__ void fill_labels_kernel(int *__restrict__ out, size_t n, uint64_t seed, uint64_t offset, int n_classes) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = (int)(splitmix64_at(seed, offset + i) % (uint64_t)n_classes);
+}
+
+extern "C" {
+int mid_maxpool_fwd(mid_stream s, const float *x, float *y, int *max_inds, int N, int C, int H, int k, int stride) {
+    const int Ho = H / stride;
+    const size_t total = (size_t)N * C * Ho * Ho;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)s, x, y, max_inds, N * C, H, Ho, k, stride);
+    MI_LAUNCH_CHECK("maxpool_fwd_kernel");
+    return 0;
+}
+int mid_maxpool_bwd(mid_stream s, const int *max_inds, const float *dy, float *dx, int N, int C, int H, int k, int stride) {
+    const int Ho = H / stride;
+    const size_t total = (size_t)N * C * H * H;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)s, max_inds, dy, dx, N * C, H, Ho, k, stride);
+    MI_LAUNCH_CHECK("maxpool_bwd_kernel");
+    return 0;
+}
+int mid_avgpool_fwd(mid_stream s, const float *x, float *y, int N, int C, int P) {
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(mi_cdiv((long)N * C, 4)), dim3(256), 0, (hipStream_t)s, x, y, N * C, P);
+    MI_LAUNCH_CHECK("avgpool_fwd_kernel");
+    return 0;
+}
+int mid_avgpool_bwd(mid_stream s, const float *dy, float *dx, int N, int C, int P) {
+    const size_t total = (size_t)N * C * P;
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)s, dy, dx, total, P);
+    MI_LAUNCH_CHECK("avgpool_bwd_kernel");
+    return 0;
+}
+int mid_relu_deriv(mid_stream s, const float *x, const float *up, float *out, size_t n) {
+    hipLaunchKernelGGL(relu_deriv_kernel, dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, (hipStream_t)s, x, up, out, n);
+    MI_LAUNCH_CHECK("relu_deriv_kernel");
+    return 0;
+}
+int mid_add_relu(mid_stream s, const float *a, const float *b, float *sum_out, float *act_out, size_t n) {
+    hipLaunchKernelGGL(add_relu_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)s, a, b, sum_out, act_out, n);
+    MI_LAUNCH_CHECK("add_relu_kernel");
+    return 0;
+}
+int mid_softmax(mid_stream s, const float *x, float *out, int N, int L) {
+    hipLaunchKernelGGL(softmax_kernel, dim3(N), dim3(64), 0, (hipStream_t)s, x, out, L);
+    MI_LAUNCH_CHECK("softmax_kernel");
+    return 0;
+}
+int mid_ce_deriv(mid_stream s, const float *pred, const int *labels, float *d, int N, int L) {
+    hipLaunchKernelGGL(ce_deriv_kernel, dim3(ew_blocks((size_t)N * L)), dim3(256), 0, (hipStream_t)s, pred, labels, d, N, L);
+    MI_LAUNCH_CHECK("ce_deriv_kernel");
+    return 0;
+}
+int mid_adam(mid_stream s, float *p, const float *g, float *m, float *v, size_t n, float lr, float wd, float b1, float b2,
+             float cur_b1, float cur_b2, float eps, int *nan_flag) {
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)s, p, g, m, v, n, lr, wd, b1, b2, cur_b1, cur_b2, eps, nan_flag);
+    MI_LAUNCH_CHECK("adam_kernel");
+    return 0;
+}
+int mid_nhwc_to_nchw(mid_stream s, const float *in, float *out, int N, int H, int W, int C) {
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ew_blocks((size_t)N * H * W * C)), dim3(256), 0, (hipStream_t)s, in, out, N, H * W, C);
+    MI_LAUNCH_CHECK("nhwc_to_nchw_kernel");
+    return 0;
+}
+int mid_nchw_to_nhwc(mid_stream s, const float *in, float *out, int N, int C, int H, int W) {
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_blocks((size_t)N * H * W * C)), dim3(256), 0, (hipStream_t)s, in, out, N, C, H * W);
+    MI_LAUNCH_CHECK("nchw_to_nhwc_kernel");
+    return 0;
+}
+int mid_fill_uniform(mid_stream s, float *out, size_t n, uint64_t seed, uint64_t offset, float lo, float hi) {
+    hipLaunchKernelGGL(fill_uniform_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)s, out, n, seed, offset, lo, hi);
+    MI_LAUNCH_CHECK("fill_uniform_kernel");
+    return 0;
+}
+int mid_fill_labels(mid_stream s, int *out, size_t n, uint64_t seed, uint64_t offset, int n_classes) {
+    hipLaunchKernelGGL(fill_labels_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)s, out, n, seed, offset, n_classes);
+    MI_LAUNCH_CHECK("fill_labels_kernel");
+    return 0;
+}
+}

@@ -1,0 +1,121 @@
+/*
+ * mi_device.h -- the thin header layer between the C host code (trainer.c, loader.c, ...) and the
+ * HIP side (runtime.hip + kernels_*.hip).  Host .c files include only this; they never see HIP
+ * headers.  It plays the role of the cuda_runtime.h include of resnet.cu:5-7 plus the
+ * prepareAndDo* launch wrappers of resnet.cu:1386-1509.
+ * All launches are asynchronous on the given stream; errors are recorded (mid_last_error).
+ */
+#ifndef MI_DEVICE_H
+#define MI_DEVICE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *mid_stream;
+typedef void *mid_event;
+
+/* ---- runtime ---- */
+int mid_device_count(void);
+int mid_set_device(int dev);
+const char *mid_last_error(void);
+void mid_clear_error(void);
+void *mid_malloc(size_t bytes);
+void mid_free(void *p);
+void *mid_malloc_host(size_t bytes); /* pinned */
+void mid_free_host(void *p);
+void mid_memcpy_h2d(void *dst, const void *src, size_t bytes, mid_stream s);
+void mid_memcpy_d2h(void *dst, const void *src, size_t bytes, mid_stream s);
+void mid_memcpy_d2d(void *dst, const void *src, size_t bytes, mid_stream s);
+void mid_memset(void *dst, int byte, size_t bytes, mid_stream s);
+mid_stream mid_stream_create(void);
+void mid_stream_destroy(mid_stream s);
+void mid_stream_sync(mid_stream s);
+void mid_device_sync(void);
+mid_event mid_event_create(void);
+void mid_event_destroy(mid_event e);
+void mid_event_record(mid_event e, mid_stream s);
+void mid_stream_wait_event(mid_stream s, mid_event e);
+float mid_event_elapsed_ms(mid_event a, mid_event b);
+void mid_event_sync(mid_event e);
+
+/* ---- optional per-kernel-family timing (HIP events around each launch, on the launch stream) ----
+ * families: 0 direct conv fwd/dgrad, 1 direct conv wgrad, 2 MFMA GEMM (1x1 conv, FC), 3 batch norm, 4 other */
+void mid_prof_enable(int on);
+void mid_prof_reset(void);
+/* resolves pending events (synchronises) and returns totals since the last reset */
+void mid_prof_get(int family, long *launches, double *ms, double *flops, double *bytes);
+
+/* ---- workspace a conv launch may use (transformed weights, split partials) ---- */
+typedef struct {
+    float *wt;        /* transformed-weight scratch */
+    size_t wt_floats;
+    float *part;      /* split-reduction partial sums */
+    size_t part_floats;
+} mid_workspace;
+
+/* ---- convolution (NCHW activations, KCRS weights), square images/kernels, pad k/2, Ho = H/stride ---- */
+/* 3x3 / 7x7 direct (LDS-tiled, no MFMA); 1x1 goes to the MFMA GEMM.  Returns 0 ok, <0 unsupported shape. */
+int mid_conv_fwd(mid_stream s, mid_workspace *ws, const float *x, const float *w, float *y, int N, int C, int H, int K,
+                 int k, int stride);
+/* dx = dgrad (+ addend when addend != NULL; addend may alias dx) */
+int mid_conv_dgrad(mid_stream s, mid_workspace *ws, const float *w, const float *dy, float *dx, const float *addend,
+                   int N, int C, int H, int K, int k, int stride);
+int mid_conv_wgrad(mid_stream s, mid_workspace *ws, const float *x, const float *dy, float *dw, int N, int C, int H,
+                   int K, int k, int stride);
+/* sizes a workspace must have for the given layer (floats) */
+size_t mid_conv_ws_wt_floats(int C, int K, int k);
+size_t mid_conv_ws_part_floats(int N, int C, int H, int K, int k, int stride);
+
+/* ---- plain GEMMs for the FC layer (row-major) ---- */
+/* out[m x n] = A[m x k] B[k x n] */
+int mid_gemm_nn(mid_stream s, const float *A, const float *B, float *out, int m, int k, int n);
+/* out[m x n] = At^T B, At is [k x m] */
+int mid_gemm_tn(mid_stream s, const float *At, const float *B, float *out, int m, int k, int n);
+/* out[m x n] = A Bt^T, Bt is [n x k] */
+int mid_gemm_nt(mid_stream s, const float *A, const float *Bt, float *out, int m, int k, int n);
+
+/* ---- batch norm (training mode, biased variance, per-replica statistics) ---- */
+/* stats_ws: >= mid_bn_ws_floats(C) floats of scratch */
+size_t mid_bn_ws_floats(int C);
+/* y = [relu](gamma * (x-mean)/sqrt(var+eps) + beta) [+ residual, relu]; writes means/vars.
+ * residual != NULL => y = relu(bn(x) + residual).  xhat_out / norm_out optional (full-store). */
+int mid_bn_fwd(mid_stream s, float *stats_ws, const float *x, const float *gamma, const float *beta,
+               const float *residual, float *means, float *vars, float *y, float *xhat_out, float *norm_out, int N,
+               int C, int P, float eps, int relu);
+/* mask_mode 0 none; 1 recompute own ReLU mask from x; 2 gate dy by mask_src > 0 */
+int mid_bn_bwd(mid_stream s, float *stats_ws, const float *x, const float *gamma, const float *beta,
+               const float *means, const float *vars, const float *dy, const float *mask_src, float *dx,
+               float *dgamma, float *dbeta, int N, int C, int P, float eps, int mask_mode);
+
+/* ---- pools, elementwise, loss, optimizer ---- */
+int mid_maxpool_fwd(mid_stream s, const float *x, float *y, int *max_inds, int N, int C, int H, int k, int stride);
+int mid_maxpool_bwd(mid_stream s, const int *max_inds, const float *dy, float *dx, int N, int C, int H, int k,
+                    int stride);
+int mid_avgpool_fwd(mid_stream s, const float *x, float *y, int N, int C, int P);
+int mid_avgpool_bwd(mid_stream s, const float *dy, float *dx, int N, int C, int P);
+int mid_relu_deriv(mid_stream s, const float *x, const float *up, float *out, size_t n);
+int mid_add_relu(mid_stream s, const float *a, const float *b, float *sum_out, float *act_out, size_t n);
+int mid_softmax(mid_stream s, const float *x, float *out, int N, int L);
+int mid_ce_deriv(mid_stream s, const float *pred, const int *labels, float *d, int N, int L);
+/* fused updateMeans+updateVars+updateParams (resnet.cu:605-662); sets *nan_flag (device int) on NaN/Inf */
+int mid_adam(mid_stream s, float *p, const float *g, float *m, float *v, size_t n, float lr, float wd, float b1,
+             float b2, float cur_b1, float cur_b2, float eps, int *nan_flag);
+int mid_nhwc_to_nchw(mid_stream s, const float *in, float *out, int N, int H, int W, int C);
+int mid_nchw_to_nhwc(mid_stream s, const float *in, float *out, int N, int C, int H, int W);
+/* splitmix64 counter streams on device (synthetic batches): uniform in [lo,hi) / labels mod n_classes */
+int mid_fill_uniform(mid_stream s, float *out, size_t n, uint64_t seed, uint64_t offset, float lo, float hi);
+int mid_fill_labels(mid_stream s, int *out, size_t n, uint64_t seed, uint64_t offset, int n_classes);
+
+/* ---- RCCL (resolved with dlopen at first use) ---- */
+int mid_rccl_unique_id_bytes(void);
+int mid_rccl_get_unique_id(void *out, int bytes);
+void *mid_rccl_comm_init(int rank, int world, const void *unique_id, int bytes);
+int mid_rccl_allreduce_sum(void *comm, float *buf, size_t count, mid_stream s);
+void mid_rccl_comm_destroy(void *comm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

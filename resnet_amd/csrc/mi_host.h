@@ -1,0 +1,69 @@
+/* mi_host.h -- internal host-side state shared by trainer.c / loader.c / dump.c / ops.c (plain C). */
+#ifndef MI_HOST_H
+#define MI_HOST_H
+#include "mi_device.h"
+#include "resnet_mi.h"
+
+struct MiRng { uint64_t seed; uint64_t counter; };
+
+/* splitmix64 counter streams (synth.c) -- identical to tests/synth.py */
+uint64_t mi_splitmix64_at(uint64_t seed, uint64_t i);
+void mi_synth_uniform(float *out, size_t n, uint64_t seed, uint64_t offset, float lo, float hi);
+void mi_synth_normal(float *out, size_t n, uint64_t seed, uint64_t offset, double var);
+void mi_synth_labels(int *out, size_t n, uint64_t seed, uint64_t offset, int n_classes);
+
+/* process-wide device state: one compute stream (everything the reference put on the default stream),
+ * one communication stream (RCCL), one copy stream (H2D of the next batch) */
+typedef struct {
+    int ready;
+    mid_stream compute, comm, copy;
+} MiGlobal;
+MiGlobal *mi_global(void);
+
+/* data source attached to a Batch (the reference hard-codes its shard path, resnet.cu:1275) */
+typedef struct BatchExt {
+    Batch *batch;
+    int source, layout, status;
+    char *shard_dir, *images_path, *labels_path;
+    uint64_t seed_images, seed_labels;
+    int n_classes, pool_batches, pool_next;
+    float *pool_images; /* device, NCHW, pool_batches * n_images * image_size */
+    int *pool_labels;   /* device */
+    int *pool_labels_host;
+    float *stage_dev;   /* device staging for NHWC -> NCHW */
+    uint64_t synth_step;
+    struct BatchExt *next;
+} BatchExt;
+BatchExt *mi_batch_ext(Batch *b);
+void mi_batch_ext_free(Batch *b);
+
+typedef struct MiCtx {
+    mid_workspace ws;
+    float *bn_ws;
+    int *nan_flag_dev, *nan_flag_host;
+    int full_store, dump_every, input_reset;
+    char *dump_root;
+    /* every device allocation of this trainer (freed by destroy_trainer) */
+    void **allocs;
+    int n_allocs, cap_allocs;
+    /* contiguous parameter-shaped arenas with identical offsets: params, grads, m, v */
+    size_t arena_floats;
+    float *g_arena, *m_arena, *v_arena;
+    /* data parallel */
+    void *comm;
+    int rank, world;
+    size_t bucket_bytes;
+    size_t dp_cursor; /* floats: gradients [dp_cursor, arena_floats) already handed to RCCL */
+    mid_event ev_grads, ev_reduced;
+    int dp_pending;
+    /* timing */
+    mid_event ev_t[6];
+    float last_ms[5];
+} MiCtx;
+
+void *mi_ctx_alloc(MiCtx *c, size_t bytes);
+size_t mi_params_arena_floats(const Params *p);
+float *mi_params_arena_base(const Params *p);
+void mi_dp_reduce_ready(Train_ResNet *t, size_t from_float_offset, int force);
+
+#endif

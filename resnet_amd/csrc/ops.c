@@ -1,0 +1,87 @@
+/*
+ * ops.c -- operator layer of the C-ABI (the prepareAndDo* wrappers of resnet.cu:1386-1509 as callable
+ * entry points): each call runs one kernel family on the library's compute stream with a private
+ * workspace and returns after the stream has drained.  Used by the parity tests to drive every HIP
+ * kernel on its own; the trainer itself calls the mid_* launchers directly (no sync, shared workspace).
+ */
+#include <stdlib.h>
+#include "mi_host.h"
+
+void *mi_malloc(size_t bytes) { return mid_malloc(bytes); }
+void mi_free(void *p) { mid_free(p); }
+
+static int finish(int rc) {
+    mid_stream_sync(mi_global()->compute);
+    if (rc) return rc;
+    return mid_last_error()[0] ? -1 : 0;
+}
+static int ws_make(mid_workspace *ws, size_t wt, size_t part) {
+    ws->wt_floats = wt; ws->part_floats = part;
+    ws->wt = wt ? (float *)mid_malloc(wt * sizeof(float)) : NULL;
+    ws->part = part ? (float *)mid_malloc(part * sizeof(float)) : NULL;
+    return (wt && !ws->wt) || (part && !ws->part);
+}
+static void ws_free(mid_workspace *ws) { mid_free(ws->wt); mid_free(ws->part); }
+
+int mi_op_conv_fwd(const float *x, const float *w, float *y, int N, int C, int H, int K, int k, int stride) {
+    mid_workspace ws;
+    if (ws_make(&ws, mid_conv_ws_wt_floats(C, K, k), 0)) return -3;
+    int rc = finish(mid_conv_fwd(mi_global()->compute, &ws, x, w, y, N, C, H, K, k, stride));
+    ws_free(&ws);
+    return rc;
+}
+int mi_op_conv_dgrad(const float *w, const float *dy, float *dx, int N, int C, int H, int K, int k, int stride, int to_add) {
+    mid_workspace ws;
+    if (ws_make(&ws, mid_conv_ws_wt_floats(C, K, k), 0)) return -3;
+    int rc = finish(mid_conv_dgrad(mi_global()->compute, &ws, w, dy, dx, to_add ? dx : NULL, N, C, H, K, k, stride));
+    ws_free(&ws);
+    return rc;
+}
+int mi_op_conv_wgrad(const float *x, const float *dy, float *dw, int N, int C, int H, int K, int k, int stride) {
+    mid_workspace ws;
+    if (ws_make(&ws, 0, mid_conv_ws_part_floats(N, C, H, K, k, stride))) return -3;
+    int rc = finish(mid_conv_wgrad(mi_global()->compute, &ws, x, dy, dw, N, C, H, K, k, stride));
+    ws_free(&ws);
+    return rc;
+}
+int mi_op_bn_fwd(const float *x, const float *gamma, const float *beta, float *means, float *vars, float *y, int N, int C,
+                 int H, float eps, int relu) {
+    float *ws = (float *)mid_malloc(mid_bn_ws_floats(C) * sizeof(float));
+    int rc = finish(mid_bn_fwd(mi_global()->compute, ws, x, gamma, beta, NULL, means, vars, y, NULL, NULL, N, C, H * H, eps, relu));
+    mid_free(ws);
+    return rc;
+}
+int mi_op_bn_fwd_add_relu(const float *x, const float *gamma, const float *beta, const float *residual, float *means,
+                          float *vars, float *y, int N, int C, int H, float eps) {
+    float *ws = (float *)mid_malloc(mid_bn_ws_floats(C) * sizeof(float));
+    int rc = finish(mid_bn_fwd(mi_global()->compute, ws, x, gamma, beta, residual, means, vars, y, NULL, NULL, N, C, H * H, eps, 0));
+    mid_free(ws);
+    return rc;
+}
+int mi_op_bn_bwd(const float *x, const float *gamma, const float *beta, const float *means, const float *vars,
+                 const float *dy, const float *mask_src, float *dx, float *dgamma, float *dbeta, int N, int C, int H,
+                 float eps, int mask_mode) {
+    float *ws = (float *)mid_malloc(mid_bn_ws_floats(C) * sizeof(float));
+    int rc = finish(mid_bn_bwd(mi_global()->compute, ws, x, gamma, beta, means, vars, dy, mask_src, dx, dgamma, dbeta, N, C, H * H, eps, mask_mode));
+    mid_free(ws);
+    return rc;
+}
+int mi_op_maxpool_fwd(const float *x, float *y, int *max_inds, int N, int C, int H, int k, int stride) {
+    return finish(mid_maxpool_fwd(mi_global()->compute, x, y, max_inds, N, C, H, k, stride));
+}
+int mi_op_maxpool_bwd(const int *max_inds, const float *dy, float *dx, int N, int C, int H, int k, int stride) {
+    return finish(mid_maxpool_bwd(mi_global()->compute, max_inds, dy, dx, N, C, H, k, stride));
+}
+int mi_op_avgpool_fwd(const float *x, float *y, int N, int C, int H) { return finish(mid_avgpool_fwd(mi_global()->compute, x, y, N, C, H * H)); }
+int mi_op_avgpool_bwd(const float *dy, float *dx, int N, int C, int H) { return finish(mid_avgpool_bwd(mi_global()->compute, dy, dx, N, C, H * H)); }
+int mi_op_relu_deriv(const float *x, const float *up, float *out, size_t n) { return finish(mid_relu_deriv(mi_global()->compute, x, up, out, n)); }
+int mi_op_matmul(const float *A, const float *B, float *out, int m, int k, int n) { return finish(mid_gemm_nn(mi_global()->compute, A, B, out, m, k, n)); }
+int mi_op_matmul_lt(const float *A_kxm, const float *B, float *out, int m, int k, int n) { return finish(mid_gemm_tn(mi_global()->compute, A_kxm, B, out, m, k, n)); }
+int mi_op_matmul_rt(const float *A, const float *B_nxk, float *out, int m, int k, int n) { return finish(mid_gemm_nt(mi_global()->compute, A, B_nxk, out, m, k, n)); }
+int mi_op_softmax(const float *x, float *out, int N, int L) { return finish(mid_softmax(mi_global()->compute, x, out, N, L)); }
+int mi_op_ce_deriv(const float *pred, const int *labels, float *d, int N, int L) { return finish(mid_ce_deriv(mi_global()->compute, pred, labels, d, N, L)); }
+int mi_op_adam(float *p, const float *g, float *m, float *v, size_t n, float lr, float wd, float b1, float b2, float cur_b1,
+               float cur_b2, float eps, int *nan_flag_dev) {
+    return finish(mid_adam(mi_global()->compute, p, g, m, v, n, lr, wd, b1, b2, cur_b1, cur_b2, eps, nan_flag_dev));
+}
+int mi_op_nhwc_to_nchw(const float *in, float *out, int N, int H, int W, int C) { return finish(mid_nhwc_to_nchw(mi_global()->compute, in, out, N, H, W, C)); }

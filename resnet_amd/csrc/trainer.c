@@ -1,0 +1,659 @@
+/*
+ * trainer.c -- host side of the drop-in trainer surface, in C over the thin device header (mi_device.h).
+ * Mirrors the reference's L3/L4 layers: init_dimensions / init_resnet / init_trainer (resnet.cu:666-1194),
+ * forward_pass (resnet.cu:1526-1775), backwards_pass (resnet.cu:1777-2248 with the spatial-BN fix of
+ * resnet_cudnn.cu:2365-2366), update_parameters (resnet.cu:2910-2987).
+ *
+ * What is deliberately different from the reference (same results, MI355X-first structure):
+ *  - one stream-ordered launch sequence, no cudaMalloc/cudaFree or blocking copies inside a step
+ *    (the reference mallocs in FC backward, resnet.cu:1484-1508, and leaks in :2080);
+ *  - parameters / gradients / Adam moments live in four contiguous arenas with identical offsets, so the
+ *    480 Adam launches + 160 memsets + per-tensor D2H NaN scans of resnet.cu:2952-2978 are one launch, one
+ *    memset and one 4-byte flag, and the gradient all-reduce runs over contiguous buckets;
+ *  - BN stores only what backward needs (conv output, mean, var, activated); x-hat / BN-out / pre-ReLU
+ *    sums exist only in full-store mode; BN+residual-add+ReLU is one kernel; ReLU' is fused into BN';
+ *  - activation derivatives use six rolling buffers (the policy of resnet_cudnn_lowmem.cu:2152-2170)
+ *    instead of a full mirror of the activation tree (resnet.cu:1151).
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "mi_host.h"
+
+static MiGlobal G;
+MiGlobal *mi_global(void) {
+    if (!G.ready) {
+        G.compute = mid_stream_create();
+        G.comm = mid_stream_create();
+        G.copy = mid_stream_create();
+        G.ready = 1;
+    }
+    return &G;
+}
+
+int mi_device_count(void) { return mid_device_count(); }
+int mi_set_device(int device) { return mid_set_device(device); }
+const char *mi_last_error(void) { return mid_last_error(); }
+void mi_device_synchronize(void) { mid_device_sync(); }
+void mi_copy_to_device(void *d, const void *s, size_t n) { MiGlobal *g = mi_global(); mid_memcpy_h2d(d, s, n, g->compute); mid_stream_sync(g->compute); }
+void mi_copy_to_host(void *d, const void *s, size_t n) { MiGlobal *g = mi_global(); mid_memcpy_d2h(d, s, n, g->compute); mid_stream_sync(g->compute); }
+
+void mi_prof_enable(int on) { mid_prof_enable(on); }
+void mi_prof_reset(void) { mid_prof_reset(); }
+void mi_prof_get(int family, long *launches, double *ms, double *flops, double *bytes) { mid_prof_get(family, launches, ms, flops, bytes); }
+
+MiRng *mi_rng_create(uint64_t seed) {
+    MiRng *r = (MiRng *)calloc(1, sizeof(MiRng));
+    r->seed = seed;
+    return r;
+}
+void mi_rng_destroy(MiRng *r) { free(r); }
+
+void *mi_ctx_alloc(MiCtx *c, size_t bytes) {
+    void *p = mid_malloc(bytes);
+    if (!p) { fprintf(stderr, "resnet_mi: device allocation of %zu bytes failed: %s\n", bytes, mid_last_error()); exit(1); }
+    if (c) {
+        if (c->n_allocs == c->cap_allocs) {
+            c->cap_allocs = c->cap_allocs ? c->cap_allocs * 2 : 256;
+            c->allocs = (void **)realloc(c->allocs, sizeof(void *) * c->cap_allocs);
+        }
+        c->allocs[c->n_allocs++] = p;
+    }
+    return p;
+}
+
+/* resnet.cu:666-682 */
+Dims *init_dimensions(int input, int init_kernel_dim, int init_conv_filters, int init_conv_stride, int init_maxpool_dim,
+                      int init_maxpool_stride, int n_conv_blocks, int *is_block_spatial_reduction, int final_depth,
+                      int output) {
+    Dims *d = (Dims *)malloc(sizeof(Dims));
+    d->input = input; d->init_kernel_dim = init_kernel_dim; d->init_conv_filters = init_conv_filters;
+    d->init_conv_stride = init_conv_stride; d->init_maxpool_dim = init_maxpool_dim;
+    d->init_maxpool_stride = init_maxpool_stride; d->n_conv_blocks = n_conv_blocks;
+    d->is_block_spatial_reduction = is_block_spatial_reduction; d->final_depth = final_depth; d->output = output;
+    return d;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* Parameter-shaped structure over one contiguous arena.  Location order = resnet.cu:838-943.       */
+#define ARENA_ALIGN 64
+static size_t align_up(size_t v) { return (v + ARENA_ALIGN - 1) / ARENA_ALIGN * ARENA_ALIGN; }
+
+typedef struct { float *base; size_t off; float **loc; int *sizes; int n; double *var; } Carver;
+static float *carve(Carver *c, int size, double var /* <0: gamma, ==0: zero */) {
+    float *p = c->base + c->off;
+    c->loc[c->n] = p; c->sizes[c->n] = size; c->var[c->n] = var; c->n++;
+    c->off += align_up((size_t)size);
+    return p;
+}
+static BatchNorm *make_bn(Carver *c, int spatial, int depth) {
+    BatchNorm *b = (BatchNorm *)malloc(sizeof(BatchNorm));
+    b->spatial_dim = spatial; b->depth = depth;
+    b->gamma = carve(c, depth, -1.0);
+    b->beta = carve(c, depth, 0.0);
+    return b;
+}
+static int count_locations(const Dims *d, size_t *arena) {
+    int n = 3, inc = d->init_conv_filters, ex = 4 * inc, red = inc;
+    size_t a = align_up((size_t)d->init_kernel_dim * d->init_kernel_dim * inc * 3) + 2 * align_up(inc);
+    for (int i = 0; i < d->n_conv_blocks; i++) {
+        int stride = 1;
+        if (d->is_block_spatial_reduction[i] == 1) { stride = 2; red *= 2; ex *= 2; }
+        n += 9;
+        a += align_up((size_t)inc * red) + align_up((size_t)red * red * 9) + align_up((size_t)ex * red) + 4 * align_up(red) + 2 * align_up(ex);
+        if (inc != ex) { n += 3; a += align_up((size_t)inc * ex * (stride == 2 ? 9 : 1)) + 2 * align_up(ex); }
+        inc = ex;
+    }
+    n += 1;
+    a += align_up((size_t)ex * d->output);
+    *arena = a;
+    return n;
+}
+size_t mi_params_arena_floats(const Params *p) {
+    const int l = p->n_locations - 1;
+    return (size_t)(p->locations[l] - p->locations[0]) + align_up((size_t)p->sizes[l]);
+}
+float *mi_params_arena_base(const Params *p) { return p->locations[0]; }
+
+/* init_model_parameters, resnet.cu:805-949.  gen == NULL -> zero twin (gradients, Adam moments, :1148-1150) */
+static Params *build_params(const Dims *d, MiRng *gen, MiCtx *owner) {
+    size_t arena_floats;
+    const int nloc = count_locations(d, &arena_floats);
+    Params *p = (Params *)malloc(sizeof(Params));
+    Carver c;
+    c.base = (float *)mi_ctx_alloc(owner, arena_floats * sizeof(float));
+    c.off = 0; c.n = 0;
+    c.loc = (float **)malloc(sizeof(float *) * nloc);
+    c.sizes = (int *)malloc(sizeof(int) * nloc);
+    c.var = (double *)malloc(sizeof(double) * nloc);
+    const int f = d->init_conv_filters, kd = d->init_kernel_dim;
+    p->init_conv_layer = carve(&c, kd * kd * f * 3, 2.0 / (7.0 * 7.0 * (3 + f))); /* fan literal 7*7, resnet.cu:831 */
+    p->norm_init_conv = make_bn(&c, d->input / d->init_conv_stride, f);
+    p->conv_blocks = (ConvBlock **)malloc(sizeof(ConvBlock *) * (d->n_conv_blocks > 0 ? d->n_conv_blocks : 1));
+    int inc = f, H = d->input / 4, red = f, ex = 4 * f; /* resnet.cu:857-862 */
+    for (int i = 0; i < d->n_conv_blocks; i++) {
+        int stride = 1;
+        if (d->is_block_spatial_reduction[i] == 1) { stride = 2; red *= 2; ex *= 2; }
+        ConvBlock *b = (ConvBlock *)calloc(1, sizeof(ConvBlock));
+        b->incoming_filters = inc; b->incoming_spatial_dim = H; b->reduced_depth = red; b->expanded_depth = ex; b->stride = stride;
+        b->depth_reduction = carve(&c, inc * red, 2.0 / (double)(inc + red));
+        b->norm_depth_reduction = make_bn(&c, H, red);
+        b->spatial = carve(&c, red * red * 9, 2.0 / (9.0 * (red + red)));
+        b->norm_spatial = make_bn(&c, H / stride, red);
+        b->depth_expansion = carve(&c, ex * red, 2.0 / (double)(red + ex));
+        b->norm_expansion = make_bn(&c, H / stride, ex);
+        if (inc != ex) { /* resnet.cu:770-793: 3x3 stride-2 projection when the block strides, else 1x1 */
+            if (stride == 2) b->projection = carve(&c, 9 * inc * ex, 2.0 / (9.0 * (inc + ex)));
+            else b->projection = carve(&c, inc * ex, 2.0 / (double)(inc + ex));
+            b->norm_projection = make_bn(&c, H / stride, ex);
+        }
+        p->conv_blocks[i] = b;
+        if (stride == 2) H /= 2;
+        inc = ex;
+    }
+    p->fully_connected = carve(&c, ex * d->output, 1e-4); /* resnet.cu:938 */
+    p->locations = c.loc; p->sizes = c.sizes; p->n_locations = c.n;
+
+    MiGlobal *g = mi_global();
+    mid_memset(c.base, 0, arena_floats * sizeof(float), g->compute);
+    if (gen) {
+        /* tensor i draws from the stream at offset sum(sizes[0..i)) -- same rule as tests/synth.make_params */
+        size_t off = 0, maxsz = 0;
+        for (int i = 0; i < c.n; i++) if ((size_t)c.sizes[i] > maxsz) maxsz = c.sizes[i];
+        float *host = (float *)malloc(maxsz * sizeof(float));
+        for (int i = 0; i < c.n; i++) {
+            const size_t sz = c.sizes[i];
+            if (c.var[i] > 0) mi_synth_normal(host, sz, gen->seed, gen->counter + off, c.var[i]);
+            else if (c.var[i] < 0) for (size_t j = 0; j < sz; j++) host[j] = 1.0f;
+            if (c.var[i] != 0) { mid_memcpy_h2d(c.loc[i], host, sz * sizeof(float), g->compute); mid_stream_sync(g->compute); }
+            off += sz;
+        }
+        gen->counter += off;
+        free(host);
+    }
+    mid_stream_sync(g->compute);
+    free(c.var);
+    return p;
+}
+static void free_params_host(Params *p, const Dims *d) {
+    if (!p) return;
+    free(p->norm_init_conv);
+    for (int i = 0; i < d->n_conv_blocks; i++) {
+        ConvBlock *b = p->conv_blocks[i];
+        free(b->norm_depth_reduction); free(b->norm_spatial); free(b->norm_expansion); free(b->norm_projection); free(b);
+    }
+    free(p->conv_blocks); free(p->locations); free(p->sizes); free(p);
+}
+
+/* resnet.cu:951-957 */
+ResNet *init_resnet(Dims *dims, MiRng *gen) {
+    ResNet *m = (ResNet *)malloc(sizeof(ResNet));
+    MiRng tmp = {1234, 0};
+    m->dims = dims;
+    m->params = build_params(dims, gen ? gen : &tmp, NULL);
+    return m;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+static Cache_BatchNorm *make_cache(MiCtx *c, int input_size, int feature_size, int with_stats) {
+    Cache_BatchNorm *k = (Cache_BatchNorm *)calloc(1, sizeof(Cache_BatchNorm));
+    k->input_size = input_size; k->feature_size = feature_size;
+    if (with_stats) {
+        k->means = (float *)mi_ctx_alloc(c, sizeof(float) * feature_size);
+        k->vars = (float *)mi_ctx_alloc(c, sizeof(float) * feature_size);
+    }
+    return k;
+}
+static float *falloc(MiCtx *c, size_t n) { return (float *)mi_ctx_alloc(c, n * sizeof(float)); }
+
+/* init_activations, resnet.cu:1057-1113.  pool != NULL builds the derivative tree over six rolling buffers. */
+static Activations *build_activations(MiCtx *c, const Dims *d, ConvBlock **blocks, int N, float **pool) {
+    Activations *a = (Activations *)calloc(1, sizeof(Activations));
+    const int f = d->init_conv_filters, Hs = d->input / d->init_conv_stride, Hp = Hs / d->init_maxpool_stride;
+    const size_t stem = (size_t)N * f * Hs * Hs, pl = (size_t)N * f * Hp * Hp;
+    a->n_conv_blocks = d->n_conv_blocks;
+    a->activation_conv_blocks = (Activation_ConvBlock **)calloc(d->n_conv_blocks > 0 ? d->n_conv_blocks : 1, sizeof(void *));
+    if (!pool) {
+        a->init_conv_applied = falloc(c, stem);
+        a->norm_init_conv = make_cache(c, (int)stem, f, 1);
+        a->init_conv_activated = falloc(c, stem);
+        a->max_inds = (int *)mi_ctx_alloc(c, pl * sizeof(int));
+        a->init_convblock_input = falloc(c, pl);
+    } else {
+        a->init_conv_applied = pool[3];   /* B */
+        a->norm_init_conv = make_cache(c, (int)stem, f, 0);
+        a->init_conv_activated = pool[2]; /* A */
+        a->init_convblock_input = pool[0]; /* U0 */
+    }
+    for (int i = 0; i < d->n_conv_blocks; i++) {
+        const ConvBlock *b = blocks[i];
+        Activation_ConvBlock *k = (Activation_ConvBlock *)calloc(1, sizeof(Activation_ConvBlock));
+        k->incoming_filters = b->incoming_filters; k->incoming_spatial_dim = b->incoming_spatial_dim;
+        k->reduced_depth = b->reduced_depth; k->expanded_depth = b->expanded_depth; k->stride = b->stride;
+        const int H = b->incoming_spatial_dim, Ho = H / b->stride;
+        const size_t rsz = (size_t)N * b->reduced_depth * H * H, ssz = (size_t)N * b->reduced_depth * Ho * Ho,
+                     osz = (size_t)N * b->expanded_depth * Ho * Ho;
+        const int has_proj = b->projection != NULL;
+        k->norm_post_reduced = make_cache(c, (int)rsz, b->reduced_depth, !pool);
+        k->norm_post_spatial = make_cache(c, (int)ssz, b->reduced_depth, !pool);
+        k->norm_post_expanded = make_cache(c, (int)osz, b->expanded_depth, !pool);
+        if (has_proj) k->norm_post_projection = make_cache(c, (int)osz, b->expanded_depth, !pool);
+        if (!pool) {
+            k->post_reduced = falloc(c, rsz); k->post_reduced_activated = falloc(c, rsz);
+            k->post_spatial = falloc(c, ssz); k->post_spatial_activated = falloc(c, ssz);
+            k->post_expanded = falloc(c, osz);
+            if (has_proj) { k->transformed_residual = falloc(c, osz); k->post_projection_norm_vals = falloc(c, osz); }
+            k->output_activated = falloc(c, osz);
+            k->output = k->output_activated; /* pre-ReLU sum is not kept unless full-store */
+        } else {
+            /* lifetimes inside one block's backward (see backwards_pass): A,B,C,D scratch + alternating U */
+            k->output_activated = pool[(i + 1) & 1];
+            k->output = pool[5];               /* D: ReLU'-gated upstream, identity blocks only */
+            k->transformed_residual = has_proj ? pool[2] : NULL; /* A */
+            k->post_expanded = pool[3];         /* B */
+            k->post_spatial_activated = pool[4]; /* C */
+            k->post_spatial = pool[2];          /* A */
+            k->post_reduced_activated = pool[3]; /* B */
+            k->post_reduced = pool[4];          /* C */
+        }
+        a->activation_conv_blocks[i] = k;
+    }
+    a->final_conv_output_pooled = falloc(c, (size_t)N * d->final_depth);
+    if (!pool) a->linear_output = falloc(c, (size_t)N * d->output);
+    return a;
+}
+
+static size_t max_tensor_elems(const Dims *d, ConvBlock **blocks, int N) {
+    const int f = d->init_conv_filters, Hs = d->input / d->init_conv_stride;
+    size_t m = (size_t)N * f * Hs * Hs;
+    for (int i = 0; i < d->n_conv_blocks; i++) {
+        const ConvBlock *b = blocks[i];
+        const int H = b->incoming_spatial_dim, Ho = H / b->stride;
+        size_t v[3] = {(size_t)N * b->reduced_depth * H * H, (size_t)N * b->expanded_depth * Ho * Ho,
+                       (size_t)N * b->incoming_filters * H * H};
+        for (int j = 0; j < 3; j++) if (v[j] > m) m = v[j];
+    }
+    return m;
+}
+
+static void size_workspaces(MiCtx *c, const Dims *d, ConvBlock **blocks, int N) {
+    size_t wt = 0, part = 0;
+    int maxc = d->init_conv_filters;
+#define LAYER(C_, H_, K_, k_, s_)                                                             \
+    do {                                                                                      \
+        size_t a_ = mid_conv_ws_wt_floats(C_, K_, k_), b_ = mid_conv_ws_part_floats(N, C_, H_, K_, k_, s_); \
+        if (a_ > wt) wt = a_;                                                                 \
+        if (b_ > part) part = b_;                                                             \
+        if ((K_) > maxc) maxc = (K_);                                                         \
+    } while (0)
+    LAYER(3, d->input, d->init_conv_filters, d->init_kernel_dim, d->init_conv_stride);
+    for (int i = 0; i < d->n_conv_blocks; i++) {
+        const ConvBlock *b = blocks[i];
+        const int H = b->incoming_spatial_dim;
+        LAYER(b->incoming_filters, H, b->reduced_depth, 1, 1);
+        LAYER(b->reduced_depth, H, b->reduced_depth, 3, b->stride);
+        LAYER(b->reduced_depth, H / b->stride, b->expanded_depth, 1, 1);
+        if (b->projection) LAYER(b->incoming_filters, H, b->expanded_depth, b->stride == 2 ? 3 : 1, b->stride);
+    }
+#undef LAYER
+    c->ws.wt_floats = wt; c->ws.part_floats = part;
+    c->ws.wt = wt ? falloc(c, wt) : NULL;
+    c->ws.part = part ? falloc(c, part) : NULL;
+    c->bn_ws = falloc(c, mid_bn_ws_floats(maxc));
+}
+
+/* resnet.cu:1157-1194 */
+Train_ResNet *init_trainer(ResNet *model, Batch *cur_batch, int batch_size, float learning_rate, float weight_decay,
+                           float mean_decay, float var_decay, float eps, int n_epochs, const char *dump_dir) {
+    Train_ResNet *t = (Train_ResNet *)calloc(1, sizeof(Train_ResNet));
+    MiCtx *c = (MiCtx *)calloc(1, sizeof(MiCtx));
+    Dims *d = model->dims;
+    ConvBlock **blocks = model->params->conv_blocks;
+    mi_global();
+    t->backend_ctx = c;
+    t->model = model; t->cur_batch = cur_batch; t->batch_size = batch_size;
+    c->dump_every = 1000; /* resnet.cu:2947 */
+    c->input_reset = 1;   /* resnet.cu:2981-2982 */
+    c->world = 1; c->bucket_bytes = (size_t)32 << 20;
+
+    Forward_Buffer *fb = (Forward_Buffer *)calloc(1, sizeof(Forward_Buffer));
+    fb->activations = build_activations(c, d, blocks, batch_size, NULL);
+    fb->pred = falloc(c, (size_t)batch_size * d->output); /* reference over-allocates N^2*output (:1126, hazard h4) */
+    fb->pred_cpu = (float *)mid_malloc_host((size_t)batch_size * d->output * sizeof(float));
+    t->forward_buffer = fb;
+
+    Backprop_Buffer *bb = (Backprop_Buffer *)calloc(1, sizeof(Backprop_Buffer));
+    bb->output_layer_deriv = falloc(c, (size_t)batch_size * d->output);
+    bb->param_derivs = build_params(d, NULL, c);
+    bb->prev_means = build_params(d, NULL, c);
+    bb->prev_vars = build_params(d, NULL, c);
+    c->arena_floats = mi_params_arena_floats(model->params);
+    c->g_arena = mi_params_arena_base(bb->param_derivs);
+    c->m_arena = mi_params_arena_base(bb->prev_means);
+    c->v_arena = mi_params_arena_base(bb->prev_vars);
+    const size_t maxe = max_tensor_elems(d, blocks, batch_size);
+    float *pool[6];
+    for (int i = 0; i < 6; i++) pool[i] = falloc(c, maxe);
+    bb->activation_derivs = build_activations(c, d, blocks, batch_size, pool);
+    t->backprop_buffer = bb;
+    size_workspaces(c, d, blocks, batch_size);
+    c->nan_flag_dev = (int *)mi_ctx_alloc(c, sizeof(int));
+    c->nan_flag_host = (int *)mid_malloc_host(sizeof(int));
+    mid_memset(c->nan_flag_dev, 0, sizeof(int), G.compute);
+    c->ev_grads = mid_event_create(); c->ev_reduced = mid_event_create();
+    for (int i = 0; i < 6; i++) c->ev_t[i] = mid_event_create();
+
+    t->learning_rate = learning_rate; t->weight_decay = weight_decay;
+    t->base_mean_decay = mean_decay; t->base_var_decay = var_decay;
+    t->cur_mean_decay = 1; t->cur_var_decay = 1;
+    t->eps = eps; t->n_epochs = n_epochs; t->cur_dump_id = -1; t->cur_epoch = 0;
+    t->loss_per_epoch = (float *)calloc(n_epochs > 0 ? n_epochs : 1, sizeof(float));
+    t->accuracy_per_epoch = (float *)calloc(n_epochs > 0 ? n_epochs : 1, sizeof(float));
+    t->init_loaded = 0;
+    t->dump_dir = dump_dir;
+    mid_stream_sync(G.compute);
+    return t;
+}
+Train_ResNet *init_trainer_cudnn_abi(ResNet *model, Batch *cur_batch, int batch_size, float learning_rate,
+                                     float weight_decay, float mean_decay, float var_decay, float eps, int n_epochs,
+                                     void *handle, const char *dump_dir) {
+    (void)handle;
+    return init_trainer(model, cur_batch, batch_size, learning_rate, weight_decay, mean_decay, var_decay, eps, n_epochs, dump_dir);
+}
+
+static MiCtx *ctx_of(Train_ResNet *t) { return (MiCtx *)t->backend_ctx; }
+
+void mi_trainer_set_full_store(Train_ResNet *t, int on) {
+    MiCtx *c = ctx_of(t);
+    if (!on || c->full_store) { c->full_store = on; return; }
+    c->full_store = 1;
+    Activations *a = t->forward_buffer->activations;
+#define EXTRA(cache) do { (cache)->normalized_temp = falloc(c, (cache)->input_size); (cache)->normalized = falloc(c, (cache)->input_size); } while (0)
+    EXTRA(a->norm_init_conv);
+    for (int i = 0; i < a->n_conv_blocks; i++) {
+        Activation_ConvBlock *k = a->activation_conv_blocks[i];
+        EXTRA(k->norm_post_reduced); EXTRA(k->norm_post_spatial); EXTRA(k->norm_post_expanded);
+        if (k->norm_post_projection) EXTRA(k->norm_post_projection);
+        k->post_expanded_norm_vals = falloc(c, k->norm_post_expanded->input_size);
+        k->output = falloc(c, k->norm_post_expanded->input_size);
+    }
+#undef EXTRA
+}
+void mi_trainer_set_dump_every(Train_ResNet *t, int every) { ctx_of(t)->dump_every = every; }
+void mi_trainer_set_input_reset(Train_ResNet *t, int on) { ctx_of(t)->input_reset = on; }
+void mi_trainer_set_dump_root(Train_ResNet *t, const char *root) {
+    MiCtx *c = ctx_of(t);
+    free(c->dump_root);
+    c->dump_root = root ? strdup(root) : NULL;
+}
+void mi_trainer_last_timings(Train_ResNet *t, float out_ms[5]) {
+    MiCtx *c = ctx_of(t);
+    mid_stream_sync(G.compute);
+    out_ms[0] = 0;
+    out_ms[1] = mid_event_elapsed_ms(c->ev_t[0], c->ev_t[1]);
+    out_ms[2] = mid_event_elapsed_ms(c->ev_t[2], c->ev_t[3]);
+    out_ms[3] = mid_event_elapsed_ms(c->ev_t[4], c->ev_t[5]);
+    out_ms[4] = c->last_ms[4];
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* conv + BN (+ReLU | +residual+ReLU): prepareAndDoConvolution + prepareAndDoBatchNormAndActivate     */
+static void unit_fwd(Train_ResNet *t, const float *in, const float *w, const BatchNorm *bn, Cache_BatchNorm *cache,
+                     float *conv_out, float *act_out, const float *residual, int C, int H, int K, int k, int stride,
+                     int relu) {
+    MiCtx *c = ctx_of(t);
+    const int N = t->batch_size, Ho = H / stride;
+    mid_conv_fwd(G.compute, &c->ws, in, w, conv_out, N, C, H, K, k, stride);
+    mid_bn_fwd(G.compute, c->bn_ws, conv_out, bn->gamma, bn->beta, residual, cache->means, cache->vars, act_out,
+               cache->normalized_temp, cache->normalized, N, K, Ho * Ho, t->eps, relu);
+}
+
+/* resnet.cu:1526-1775 */
+void forward_pass(Train_ResNet *t) {
+    MiCtx *c = ctx_of(t);
+    const Dims *d = t->model->dims;
+    const Params *p = t->model->params;
+    Activations *a = t->forward_buffer->activations;
+    const int N = t->batch_size, f = d->init_conv_filters;
+    mid_event_record(c->ev_t[0], G.compute);
+    unit_fwd(t, t->cur_batch->images, p->init_conv_layer, p->norm_init_conv, a->norm_init_conv, a->init_conv_applied,
+             a->init_conv_activated, NULL, 3, d->input, f, d->init_kernel_dim, d->init_conv_stride, 1);
+    const int Hs = d->input / d->init_conv_stride;
+    mid_maxpool_fwd(G.compute, a->init_conv_activated, a->init_convblock_input, a->max_inds, N, f, Hs, d->init_maxpool_dim,
+                    d->init_maxpool_stride);
+    const float *bin = a->init_convblock_input;
+    for (int i = 0; i < d->n_conv_blocks; i++) {
+        const ConvBlock *b = p->conv_blocks[i];
+        Activation_ConvBlock *k = a->activation_conv_blocks[i];
+        const int H = b->incoming_spatial_dim, Ho = H / b->stride;
+        unit_fwd(t, bin, b->depth_reduction, b->norm_depth_reduction, k->norm_post_reduced, k->post_reduced,
+                 k->post_reduced_activated, NULL, b->incoming_filters, H, b->reduced_depth, 1, 1, 1);
+        unit_fwd(t, k->post_reduced_activated, b->spatial, b->norm_spatial, k->norm_post_spatial, k->post_spatial,
+                 k->post_spatial_activated, NULL, b->reduced_depth, H, b->reduced_depth, 3, b->stride, 1);
+        const float *res = bin;
+        if (b->projection) { /* resnet.cu:1685-1704 */
+            unit_fwd(t, bin, b->projection, b->norm_projection, k->norm_post_projection, k->transformed_residual,
+                     k->post_projection_norm_vals, NULL, b->incoming_filters, H, b->expanded_depth, b->stride == 2 ? 3 : 1,
+                     b->stride, 0);
+            res = k->post_projection_norm_vals;
+        }
+        if (!c->full_store) { /* BN(expanded) + addVec + doActivation in one kernel (:1670, :1717, :1723) */
+            unit_fwd(t, k->post_spatial_activated, b->depth_expansion, b->norm_expansion, k->norm_post_expanded,
+                     k->post_expanded, k->output_activated, res, b->reduced_depth, Ho, b->expanded_depth, 1, 1, 0);
+        } else {
+            unit_fwd(t, k->post_spatial_activated, b->depth_expansion, b->norm_expansion, k->norm_post_expanded,
+                     k->post_expanded, k->post_expanded_norm_vals, NULL, b->reduced_depth, Ho, b->expanded_depth, 1, 1, 0);
+            mid_add_relu(G.compute, k->post_expanded_norm_vals, res, k->output, k->output_activated,
+                         (size_t)N * b->expanded_depth * Ho * Ho);
+        }
+        bin = k->output_activated;
+    }
+    const ConvBlock *last = p->conv_blocks[d->n_conv_blocks - 1];
+    const int Hl = last->incoming_spatial_dim; /* resnet.cu:1732 */
+    mid_avgpool_fwd(G.compute, bin, a->final_conv_output_pooled, N, d->final_depth, Hl * Hl);
+    mid_gemm_nn(G.compute, a->final_conv_output_pooled, p->fully_connected, a->linear_output, N, d->final_depth, d->output);
+    mid_softmax(G.compute, a->linear_output, t->forward_buffer->pred, N, d->output);
+    mid_event_record(c->ev_t[1], G.compute);
+    mid_memcpy_d2h(t->forward_buffer->pred_cpu, t->forward_buffer->pred, (size_t)N * d->output * sizeof(float), G.compute);
+    mid_stream_sync(G.compute); /* the reference's blocking cudaMemcpy (:1774) */
+}
+
+/* resnet.cu:3363-3383 */
+float mi_host_loss(Train_ResNet *t, int *n_wrong) {
+    const int N = t->batch_size, L = t->model->dims->output;
+    const float *pred = t->forward_buffer->pred_cpu;
+    const int *lab = t->cur_batch->correct_classes_cpu;
+    float loss = 0;
+    int wrong = 0;
+    for (int s = 0; s < N; s++) loss += -1 * logf(pred[(size_t)s * L + lab[s]]);
+    for (int s = 0; s < N; s++) {
+        const float pc = pred[(size_t)s * L + lab[s]];
+        for (int cc = 0; cc < L; cc++)
+            if (cc != lab[s] && pred[(size_t)s * L + cc] >= pc) { wrong++; break; }
+    }
+    if (n_wrong) *n_wrong = wrong;
+    return loss;
+}
+
+/* BN' (+fused ReLU') then conv' : prepareAndDoActivationAndBatchNormDeriv + prepreAndDoConvolutionDeriv */
+static void unit_bwd(Train_ResNet *t, const float *in, const float *w, const BatchNorm *bn, const Cache_BatchNorm *cache,
+                     const BatchNorm *dbn, const float *conv_out, const float *dy, const float *mask_src, int mask_mode,
+                     float *d_conv_out, float *dx, const float *addend, float *dw, int C, int H, int K, int k, int stride) {
+    MiCtx *c = ctx_of(t);
+    const int N = t->batch_size, Ho = H / stride;
+    mid_bn_bwd(G.compute, c->bn_ws, conv_out, bn->gamma, bn->beta, cache->means, cache->vars, dy, mask_src, d_conv_out,
+               dbn->gamma, dbn->beta, N, K, Ho * Ho, t->eps, mask_mode);
+    if (dx) mid_conv_dgrad(G.compute, &c->ws, w, d_conv_out, dx, addend, N, C, H, K, k, stride);
+    mid_conv_wgrad(G.compute, &c->ws, in, d_conv_out, dw, N, C, H, K, k, stride);
+}
+
+/* resnet.cu:1777-2248 */
+void backwards_pass(Train_ResNet *t) {
+    MiCtx *c = ctx_of(t);
+    const Dims *d = t->model->dims;
+    const Params *p = t->model->params;
+    Activations *a = t->forward_buffer->activations;
+    Backprop_Buffer *bb = t->backprop_buffer;
+    const Params *dp = bb->param_derivs;
+    Activations *da = bb->activation_derivs;
+    const int N = t->batch_size, L = d->output, D = d->final_depth, nb = d->n_conv_blocks;
+    mid_event_record(c->ev_t[2], G.compute);
+    c->dp_cursor = c->arena_floats;
+    /* dlogits = softmax - onehot, batch SUM (no 1/N: resnet.cu:1806-1811) */
+    mid_ce_deriv(G.compute, t->forward_buffer->pred, t->cur_batch->correct_classes, bb->output_layer_deriv, N, L);
+    /* FC: dW = pooled^T dlogits (:1823), dpooled = dlogits W^T (:1830) -- no transposed temporaries */
+    mid_gemm_tn(G.compute, a->final_conv_output_pooled, bb->output_layer_deriv, dp->fully_connected, D, N, L);
+    mid_gemm_nt(G.compute, bb->output_layer_deriv, p->fully_connected, da->final_conv_output_pooled, N, L, D);
+    mi_dp_reduce_ready(t, (size_t)(dp->fully_connected - c->g_arena), 0);
+    const ConvBlock *last = p->conv_blocks[nb - 1];
+    const int Hl = last->incoming_spatial_dim;
+    mid_avgpool_bwd(G.compute, da->final_conv_output_pooled, da->activation_conv_blocks[nb - 1]->output_activated, N, D, Hl * Hl);
+    for (int i = nb - 1; i >= 0; i--) {
+        const ConvBlock *b = p->conv_blocks[i];
+        const ConvBlock *db = dp->conv_blocks[i];
+        const Activation_ConvBlock *k = a->activation_conv_blocks[i];
+        const Activation_ConvBlock *dk = da->activation_conv_blocks[i];
+        const float *bin = i == 0 ? a->init_convblock_input : a->activation_conv_blocks[i - 1]->output_activated;
+        float *dbin = i == 0 ? da->init_convblock_input : da->activation_conv_blocks[i - 1]->output_activated;
+        const int H = b->incoming_spatial_dim, Ho = H / b->stride;
+        const float *up = dk->output_activated; /* dL/d(block output) */
+        const float *exp_dy, *exp_mask, *red_addend;
+        int exp_mode;
+        if (b->projection) {
+            /* ReLU' of the block output is fused into both BN' as an external mask (doActivationDeriv, :1934) */
+            unit_bwd(t, bin, b->projection, b->norm_projection, k->norm_post_projection, db->norm_projection,
+                     k->transformed_residual, up, k->output_activated, 2, dk->transformed_residual, dbin, NULL,
+                     db->projection, b->incoming_filters, H, b->expanded_depth, b->stride == 2 ? 3 : 1, b->stride);
+            exp_dy = up; exp_mask = k->output_activated; exp_mode = 2;
+            red_addend = dbin; /* reduce-conv dgrad accumulates onto the projection path (toAdd, :2157) */
+        } else {
+            mid_relu_deriv(G.compute, k->output_activated, up, dk->output, (size_t)N * b->expanded_depth * Ho * Ho);
+            exp_dy = dk->output; exp_mask = NULL; exp_mode = 0;
+            red_addend = dk->output; /* identity shortcut: setVal 0 + addVec (:2003-2004) folded into the dgrad epilogue */
+        }
+        unit_bwd(t, k->post_spatial_activated, b->depth_expansion, b->norm_expansion, k->norm_post_expanded,
+                 db->norm_expansion, k->post_expanded, exp_dy, exp_mask, exp_mode, dk->post_expanded,
+                 dk->post_spatial_activated, NULL, db->depth_expansion, b->reduced_depth, Ho, b->expanded_depth, 1, 1);
+        /* the call resnet.cu:2060-2083 forgot; present in resnet_cudnn.cu:2365-2366 */
+        unit_bwd(t, k->post_reduced_activated, b->spatial, b->norm_spatial, k->norm_post_spatial, db->norm_spatial,
+                 k->post_spatial, dk->post_spatial_activated, NULL, 1, dk->post_spatial, dk->post_reduced_activated, NULL,
+                 db->spatial, b->reduced_depth, H, b->reduced_depth, 3, b->stride);
+        unit_bwd(t, bin, b->depth_reduction, b->norm_depth_reduction, k->norm_post_reduced, db->norm_depth_reduction,
+                 k->post_reduced, dk->post_reduced_activated, NULL, 1, dk->post_reduced, dbin, red_addend,
+                 db->depth_reduction, b->incoming_filters, H, b->reduced_depth, 1, 1);
+        mi_dp_reduce_ready(t, (size_t)(db->depth_reduction - c->g_arena), 0);
+    }
+    const int Hs = d->input / d->init_conv_stride;
+    mid_maxpool_bwd(G.compute, a->max_inds, da->init_convblock_input, da->init_conv_activated, N, d->init_conv_filters, Hs,
+                    d->init_maxpool_dim, d->init_maxpool_stride);
+    unit_bwd(t, t->cur_batch->images, p->init_conv_layer, p->norm_init_conv, a->norm_init_conv, dp->norm_init_conv,
+             a->init_conv_applied, da->init_conv_activated, NULL, 1, da->init_conv_applied, NULL, NULL,
+             dp->init_conv_layer, 3, d->input, d->init_conv_filters, d->init_kernel_dim, d->init_conv_stride);
+    mi_dp_reduce_ready(t, 0, 1);
+    mid_event_record(c->ev_t[3], G.compute);
+}
+
+/* data parallel: hand the finished tail [from, cursor) of the gradient arena to RCCL on the comm stream as soon
+ * as it is at least one bucket (or `force`).  Gradients become ready FC-first, i.e. from the arena's end
+ * (the order update_parameters walks, resnet.cu:2952). */
+void mi_dp_reduce_ready(Train_ResNet *t, size_t from, int force) {
+    MiCtx *c = ctx_of(t);
+    if (c->world <= 1 || !c->comm) return;
+    if (from >= c->dp_cursor) return;
+    const size_t n = c->dp_cursor - from;
+    if (!force && n * sizeof(float) < c->bucket_bytes) return;
+    mid_event_record(c->ev_grads, G.compute);
+    mid_stream_wait_event(G.comm, c->ev_grads);
+    mid_rccl_allreduce_sum(c->comm, c->g_arena + from, n, G.comm);
+    c->dp_cursor = from;
+    c->dp_pending = 1;
+}
+
+void dump_trainer(int dump_id, Train_ResNet *trainer, const char *special_dir);
+
+/* resnet.cu:2910-2987 */
+void update_parameters(Train_ResNet *t) {
+    MiCtx *c = ctx_of(t);
+    const Params *p = t->model->params;
+    const float cur_b1 = t->cur_mean_decay * t->base_mean_decay; /* decays advance BEFORE use (:2920-2921) */
+    const float cur_b2 = t->cur_var_decay * t->base_var_decay;
+    if (c->dump_every > 0 && t->cur_dump_id % c->dump_every == 0) dump_trainer(t->cur_dump_id, t, t->dump_dir);
+    mid_event_record(c->ev_t[4], G.compute);
+    if (c->dp_pending) {
+        mid_event_record(c->ev_reduced, G.comm);
+        mid_stream_wait_event(G.compute, c->ev_reduced);
+        c->dp_pending = 0;
+    }
+    mid_adam(G.compute, mi_params_arena_base(p), c->g_arena, c->m_arena, c->v_arena, c->arena_floats, t->learning_rate,
+             t->weight_decay, t->base_mean_decay, t->base_var_decay, cur_b1, cur_b2, t->eps, c->nan_flag_dev);
+    mid_memset(c->g_arena, 0, c->arena_floats * sizeof(float), G.compute); /* :2972-2978 */
+    if (c->input_reset) { /* :2981-2982 */
+        mid_memset(t->cur_batch->images, 0, (size_t)t->batch_size * t->cur_batch->image_size * sizeof(float), G.compute);
+        mid_memset(t->cur_batch->correct_classes, 0, (size_t)t->batch_size * sizeof(int), G.compute);
+    }
+    mid_event_record(c->ev_t[5], G.compute);
+    mid_memcpy_d2h(c->nan_flag_host, c->nan_flag_dev, sizeof(int), G.compute);
+    mid_stream_sync(G.compute);
+    if (*c->nan_flag_host) { /* check_errors, resnet.cu:2879-2907 */
+        printf("ERROR: nan or inf found in parameters, gradients or Adam moments\n");
+        printf("Dumping data to id=99999999 and exiting...\n");
+        dump_trainer(99999999, t, t->dump_dir);
+        exit(1);
+    }
+    t->cur_mean_decay = cur_b1;
+    t->cur_var_decay = cur_b2;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+static void free_activations_host(Activations *a) {
+    if (!a) return;
+    free(a->norm_init_conv);
+    for (int i = 0; i < a->n_conv_blocks; i++) {
+        Activation_ConvBlock *k = a->activation_conv_blocks[i];
+        free(k->norm_post_reduced); free(k->norm_post_spatial); free(k->norm_post_expanded); free(k->norm_post_projection);
+        free(k);
+    }
+    free(a->activation_conv_blocks);
+    free(a);
+}
+void destroy_trainer(Train_ResNet *t) {
+    if (!t) return;
+    MiCtx *c = ctx_of(t);
+    mid_device_sync();
+    const Dims *d = t->model->dims;
+    if (c->comm) mid_rccl_comm_destroy(c->comm);
+    for (int i = 0; i < c->n_allocs; i++) mid_free(c->allocs[i]);
+    free(c->allocs);
+    mid_free_host(t->forward_buffer->pred_cpu);
+    mid_free_host(c->nan_flag_host);
+    mid_event_destroy(c->ev_grads); mid_event_destroy(c->ev_reduced);
+    for (int i = 0; i < 6; i++) mid_event_destroy(c->ev_t[i]);
+    free_activations_host(t->forward_buffer->activations);
+    free_activations_host(t->backprop_buffer->activation_derivs);
+    free_params_host(t->backprop_buffer->param_derivs, d);
+    free_params_host(t->backprop_buffer->prev_means, d);
+    free_params_host(t->backprop_buffer->prev_vars, d);
+    free(t->forward_buffer); free(t->backprop_buffer);
+    mid_free(mi_params_arena_base(t->model->params));
+    free_params_host(t->model->params, d);
+    mi_batch_ext_free(t->cur_batch);
+    free(t->model->dims); free(t->model);
+    free(t->loss_per_epoch); free(t->accuracy_per_epoch);
+    free(c->dump_root); free(c);
+    free(t);
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+int mi_dp_unique_id_bytes(void) { return mid_rccl_unique_id_bytes(); }
+int mi_dp_get_unique_id(void *out, int bytes) { return mid_rccl_get_unique_id(out, bytes); }
+int mi_dp_init(Train_ResNet *t, int rank, int world, const void *unique_id, int bytes) {
+    MiCtx *c = ctx_of(t);
+    if (world <= 1) { c->world = 1; return 0; }
+    c->comm = mid_rccl_comm_init(rank, world, unique_id, bytes);
+    if (!c->comm) return -1;
+    c->rank = rank; c->world = world;
+    return 0;
+}
+void mi_dp_set_bucket_bytes(Train_ResNet *t, size_t bytes) { ctx_of(t)->bucket_bytes = bytes; }
+int mi_dp_world(const Train_ResNet *t) { return ((MiCtx *)t->backend_ctx)->world; }

@@ -1,0 +1,165 @@
+"""numpy-in / numpy-out access to the operator layer of the C-ABI (mi_op_*, include/resnet_mi.h):
+device buffers are allocated, filled, the HIP kernel runs, results are copied back.  Arrays are NCHW
+float32 (weights KCRS).  Used by the parity tests; the trainer calls the same kernels stream-ordered."""
+import ctypes as C
+
+import numpy as np
+
+from . import binding as B
+
+
+class DeviceArray:
+    def __init__(self, lib, arr=None, shape=None, dtype=np.float32):
+        self.L = lib
+        if arr is not None:
+            arr = np.ascontiguousarray(arr)
+            shape, dtype = arr.shape, arr.dtype
+        self.shape, self.dtype = tuple(shape), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self.ptr = lib.mi_malloc(max(self.nbytes, 4))
+        if not self.ptr:
+            raise MemoryError(lib.mi_last_error().decode())
+        if arr is not None:
+            lib.mi_copy_to_device(self.ptr, arr.ctypes.data, self.nbytes)
+
+    def get(self):
+        out = np.empty(self.shape, self.dtype)
+        self.L.mi_copy_to_host(out.ctypes.data, self.ptr, self.nbytes)
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.L.mi_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Ops:
+    def __init__(self):
+        self.L = B.load()
+
+    def dev(self, arr=None, shape=None, dtype=np.float32):
+        return DeviceArray(self.L, arr, shape, dtype)
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, self.L.mi_last_error().decode()))
+
+    def conv_fwd(self, x, w, stride):
+        N, Cc, H, _ = x.shape
+        K, _, k, _ = w.shape
+        dx, dw = self.dev(x), self.dev(w)
+        dy = self.dev(shape=(N, K, H // stride, H // stride))
+        self._chk(self.L.mi_op_conv_fwd(dx.ptr, dw.ptr, dy.ptr, N, Cc, H, K, k, stride), "conv_fwd")
+        return dy.get()
+
+    def conv_dgrad(self, w, dy, H, stride, dx_init=None):
+        K, Cc, k, _ = w.shape
+        N = dy.shape[0]
+        dw_, ddy = self.dev(w), self.dev(dy)
+        ddx = self.dev(dx_init) if dx_init is not None else self.dev(shape=(N, Cc, H, H))
+        self._chk(self.L.mi_op_conv_dgrad(dw_.ptr, ddy.ptr, ddx.ptr, N, Cc, H, K, k, stride, 0 if dx_init is None else 1), "conv_dgrad")
+        return ddx.get()
+
+    def conv_wgrad(self, x, dy, k, stride):
+        N, Cc, H, _ = x.shape
+        K = dy.shape[1]
+        dx, ddy = self.dev(x), self.dev(dy)
+        dw = self.dev(shape=(K, Cc, k, k))
+        self._chk(self.L.mi_op_conv_wgrad(dx.ptr, ddy.ptr, dw.ptr, N, Cc, H, K, k, stride), "conv_wgrad")
+        return dw.get()
+
+    def bn_fwd(self, x, gamma, beta, eps, relu, residual=None):
+        N, Cc, H, _ = x.shape
+        dx, dg, db = self.dev(x), self.dev(gamma), self.dev(beta)
+        dm, dv, dy = self.dev(shape=(Cc,)), self.dev(shape=(Cc,)), self.dev(shape=x.shape)
+        if residual is None:
+            self._chk(self.L.mi_op_bn_fwd(dx.ptr, dg.ptr, db.ptr, dm.ptr, dv.ptr, dy.ptr, N, Cc, H, eps, int(relu)), "bn_fwd")
+        else:
+            dr = self.dev(residual)
+            self._chk(self.L.mi_op_bn_fwd_add_relu(dx.ptr, dg.ptr, db.ptr, dr.ptr, dm.ptr, dv.ptr, dy.ptr, N, Cc, H, eps), "bn_fwd_add_relu")
+        return dm.get(), dv.get(), dy.get()
+
+    def bn_bwd(self, x, gamma, beta, means, vars_, dy, eps, mask_mode, mask_src=None):
+        N, Cc, H, _ = x.shape
+        dx, dg, db, dm, dv, ddy = (self.dev(a) for a in (x, gamma, beta, means, vars_, dy))
+        dmask = self.dev(mask_src) if mask_src is not None else None
+        out, ogam, obet = self.dev(shape=x.shape), self.dev(shape=(Cc,)), self.dev(shape=(Cc,))
+        self._chk(self.L.mi_op_bn_bwd(dx.ptr, dg.ptr, db.ptr, dm.ptr, dv.ptr, ddy.ptr, dmask.ptr if dmask else None,
+                                      out.ptr, ogam.ptr, obet.ptr, N, Cc, H, eps, mask_mode), "bn_bwd")
+        return out.get(), ogam.get(), obet.get()
+
+    def maxpool_fwd(self, x, k, stride):
+        N, Cc, H, _ = x.shape
+        Ho = H // stride
+        dx, dy, di = self.dev(x), self.dev(shape=(N, Cc, Ho, Ho)), self.dev(shape=(N, Cc, Ho, Ho), dtype=np.int32)
+        self._chk(self.L.mi_op_maxpool_fwd(dx.ptr, dy.ptr, di.ptr, N, Cc, H, k, stride), "maxpool_fwd")
+        return dy.get(), di.get()
+
+    def maxpool_bwd(self, idx, dy, H, k, stride):
+        N, Cc = dy.shape[:2]
+        di, ddy, dx = self.dev(idx.astype(np.int32)), self.dev(dy), self.dev(shape=(N, Cc, H, H))
+        self._chk(self.L.mi_op_maxpool_bwd(di.ptr, ddy.ptr, dx.ptr, N, Cc, H, k, stride), "maxpool_bwd")
+        return dx.get()
+
+    def avgpool_fwd(self, x):
+        N, Cc, H, _ = x.shape
+        dx, dy = self.dev(x), self.dev(shape=(N, Cc))
+        self._chk(self.L.mi_op_avgpool_fwd(dx.ptr, dy.ptr, N, Cc, H), "avgpool_fwd")
+        return dy.get()
+
+    def avgpool_bwd(self, dy, H):
+        N, Cc = dy.shape
+        ddy, dx = self.dev(dy), self.dev(shape=(N, Cc, H, H))
+        self._chk(self.L.mi_op_avgpool_bwd(ddy.ptr, dx.ptr, N, Cc, H), "avgpool_bwd")
+        return dx.get()
+
+    def relu_deriv(self, x, up):
+        dx, du, do = self.dev(x), self.dev(up), self.dev(shape=x.shape)
+        self._chk(self.L.mi_op_relu_deriv(dx.ptr, du.ptr, do.ptr, x.size), "relu_deriv")
+        return do.get()
+
+    def matmul(self, a, b, mode="nn"):
+        da, db = self.dev(a), self.dev(b)
+        if mode == "nn":
+            m, k = a.shape
+            n = b.shape[1]
+            fn = self.L.mi_op_matmul
+        elif mode == "lt":  # a is [k x m]
+            k, m = a.shape
+            n = b.shape[1]
+            fn = self.L.mi_op_matmul_lt
+        else:  # "rt": b is [n x k]
+            m, k = a.shape
+            n = b.shape[0]
+            fn = self.L.mi_op_matmul_rt
+        do = self.dev(shape=(m, n))
+        self._chk(fn(da.ptr, db.ptr, do.ptr, m, k, n), "matmul_" + mode)
+        return do.get()
+
+    def softmax(self, x):
+        dx, do = self.dev(x), self.dev(shape=x.shape)
+        self._chk(self.L.mi_op_softmax(dx.ptr, do.ptr, x.shape[0], x.shape[1]), "softmax")
+        return do.get()
+
+    def ce_deriv(self, pred, labels):
+        dp, dl, dd = self.dev(pred), self.dev(labels.astype(np.int32)), self.dev(shape=pred.shape)
+        self._chk(self.L.mi_op_ce_deriv(dp.ptr, dl.ptr, dd.ptr, pred.shape[0], pred.shape[1]), "ce_deriv")
+        return dd.get()
+
+    def adam(self, p, g, m, v, lr, wd, b1, b2, cur_b1, cur_b2, eps):
+        dp, dg, dm, dv = (self.dev(a) for a in (p, g, m, v))
+        flag = self.dev(np.zeros(1, np.int32))
+        self._chk(self.L.mi_op_adam(dp.ptr, dg.ptr, dm.ptr, dv.ptr, p.size, lr, wd, b1, b2, cur_b1, cur_b2, eps, flag.ptr), "adam")
+        return dp.get(), dm.get(), dv.get(), int(flag.get()[0])
+
+    def nhwc_to_nchw(self, x):
+        N, H, W, Cc = x.shape
+        dx, do = self.dev(x), self.dev(shape=(N, Cc, H, W))
+        self._chk(self.L.mi_op_nhwc_to_nchw(dx.ptr, do.ptr, N, H, W, Cc), "nhwc_to_nchw")
+        return do.get()

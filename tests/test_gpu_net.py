@@ -1,0 +1,151 @@
+"""Whole-step parity through the drop-in trainer surface (init_* / load_new_batch / forward_pass /
+backwards_pass / update_parameters) against the CPU oracle on the same seeded synthetic batch:
+per-layer activations, loss, every gradient tensor, and parameters + Adam moments after the update.
+Config 1 (BASELINE.json configs[0]) and a 3-block net with a striding block (3x3-s2 projection,
+identity shortcut, toAdd)."""
+import numpy as np
+import pytest
+
+import synth
+from util import ACT_MAX_ABS, ACT_REL_L2, GRAD_REL_L2, LOSS_ABS, check_act, check_grad, nhwc, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+PARAM_REL_L2 = 1e-5
+HYPER = dict(lr=1e-4, wd=0.0, b1=0.9, b2=0.999, eps=1e-7)
+
+
+def _make(dims, batch, oracle, full_store=False, wd=0.0):
+    from oracle.oracle_py import OracleNet
+    from resnet_amd import Trainer
+    from resnet_amd import binding as B
+    hyper = dict(HYPER, wd=wd)
+    params = synth.make_params(dims, perturb_bn=True)
+    net = OracleNet(oracle, dims, batch)
+    net.set_hyper(hyper["lr"], hyper["wd"], hyper["b1"], hyper["b2"], hyper["eps"])
+    tr = Trainer(dims, batch, **hyper)
+    if tr.L.mi_device_count() < 1:
+        pytest.fail("no HIP device: this test must run on the MI355X box")
+    assert tr.sizes == net.sizes
+    for i, p in enumerate(params):
+        net.param(i)[:] = p
+    tr.set_params(params)
+    tr.source_host(B.MI_LAYOUT_NHWC)
+    if full_store:
+        tr.L.mi_trainer_set_full_store(tr.t, 1)
+    return net, tr
+
+
+def _step(net, tr, dims, batch, step):
+    im, lab = synth.make_batch(dims, batch, step=step)
+    net.set_batch(im, lab)
+    tr.fill_host_batch(im, lab)
+    tr.load_new_batch()
+    net.forward()
+    tr.forward()
+    tr.check()
+
+
+FWD_NAMES = ["init_conv_applied", "init_conv_activated", "init_convblock_input"]
+BLOCK_FWD = ["reduction_applied", "reduction_activated", "spatial_applied", "spatial_activated", "expanded_applied",
+             "output_activated"]
+
+
+@pytest.mark.parametrize("cfg", ["C1", "C1S"])
+def test_training_step_parity(oracle, cfg):
+    dims, batch = (synth.C1_DIMS, synth.C1_BATCH) if cfg == "C1" else (synth.C1S_DIMS, 4)
+    net, tr = _make(dims, batch, oracle)
+    try:
+        for step in range(2):
+            _step(net, tr, dims, batch, step)
+            # ---- per-layer activations ----
+            for nm in FWD_NAMES:
+                check_act(nhwc(tr.activation(nm)), net.tensor(nm), "%s step %d" % (nm, step))
+            for b in range(dims["n_conv_blocks"]):
+                for leaf in BLOCK_FWD:
+                    nm = "conv_blocks/%02d/%s" % (b, leaf)
+                    check_act(nhwc(tr.activation(nm)), net.tensor(nm), "%s step %d" % (nm, step))
+            check_act(tr.activation("final_avg_pool"), net.tensor("final_avg_pool").reshape(batch, -1), "avg pool")
+            check_act(tr.activation("fc_output"), net.tensor("fc_output").reshape(batch, -1), "logits")
+            check_act(tr.pred(), net.tensor("softmax").reshape(batch, -1), "softmax")
+            # ---- loss (host loop of resnet.cu:3363-3383 on pred_cpu) ----
+            (gl, gw), (ol, ow) = tr.loss(), net.loss()
+            assert abs(gl - ol) <= LOSS_ABS * max(1.0, abs(ol)), (gl, ol)
+            assert gw == ow
+            # ---- gradients ----
+            net.backward()
+            tr.backward()
+            tr.check()
+            for i in range(net.n_locations):
+                check_grad(tr.get("grads", i), net.grad(i), "gradient of location %d step %d" % (i, step))
+            # ---- Adam ----
+            net.update()
+            tr.update()
+            tr.check()
+            for i in range(net.n_locations):
+                # Adam's first steps are ~lr*sign(g): gradient elements near 0 amplify rounding differences
+                assert rel_l2(tr.get("params", i), net.param(i)) <= PARAM_REL_L2, "param %d" % i
+                check_grad(tr.get("means", i), net.mean(i), "adam mean %d" % i)
+                check_grad(tr.get("vars", i), net.var(i), "adam var %d" % i, rel=2 * GRAD_REL_L2)
+                assert not np.any(tr.get("grads", i)), "gradients are zeroed after the update (resnet.cu:2972-2978)"
+            assert not np.any(tr.activation("input")), "batch buffers are zeroed after the update (resnet.cu:2981)"
+    finally:
+        tr.close()
+        net.close()
+
+
+def test_full_store_matches_fast_path(oracle):
+    """full-store mode (x-hat, BN-out and pre-ReLU sums kept, unfused add) gives the same step"""
+    dims, batch = synth.C1S_DIMS, 4
+    net, tr = _make(dims, batch, oracle, full_store=True, wd=1e-3)
+    try:
+        _step(net, tr, dims, batch, 0)
+        for b in range(dims["n_conv_blocks"]):
+            for leaf in ("expanded_post_norm", "combined_output", "output_activated"):
+                nm = "conv_blocks/%02d/%s" % (b, leaf)
+                check_act(nhwc(tr.activation(nm)), net.tensor(nm), nm)
+        check_act(tr.activation("batch_norms/01/projected/means"), net.tensor("batch_norms/01/projected/means"), "proj means")
+        net.backward(); tr.backward()
+        for i in range(net.n_locations):
+            check_grad(tr.get("grads", i), net.grad(i), "gradient %d" % i)
+        net.update(); tr.update()
+        for i in range(net.n_locations):
+            assert rel_l2(tr.get("params", i), net.param(i)) <= PARAM_REL_L2
+    finally:
+        tr.close()
+        net.close()
+
+
+def test_synthetic_source_and_reproducibility():
+    """the HBM-resident synthetic pool equals the numpy stream, and two runs give identical losses"""
+    from resnet_amd import Trainer
+    dims, batch = synth.C1_DIMS, 4
+    losses = []
+    for _ in range(2):
+        tr = Trainer(dims, batch, seed=1236)
+        tr.source_synthetic(1234, 1235, pool_batches=2)
+        tr.load_new_batch()
+        n = batch * 3 * 32 * 32
+        assert np.array_equal(tr.activation("input").ravel(), synth.uniform(1234, n, -124.0, 152.0))
+        assert np.array_equal(tr.labels(), synth.labels(1235, batch, 1000))
+        run = []
+        for _s in range(3):
+            tr.forward(); run.append(tr.loss()[0]); tr.backward(); tr.update(); tr.load_new_batch()
+        tr.check()
+        losses.append(run)
+        # weights come from the same counter stream as tests/synth.make_params
+        assert np.allclose(Trainer.get(tr, "means", 0), Trainer.get(tr, "means", 0))
+        tr.close()
+    assert losses[0] == losses[1], "bitwise reproducible (no atomics, fixed reduction order)"
+    assert all(np.isfinite(losses[0]))
+
+
+def test_weight_init_matches_stream():
+    from resnet_amd import Trainer
+    dims = synth.C1_DIMS
+    tr = Trainer(dims, 4, seed=1236)
+    ref = synth.make_params(dims, seed=1236)
+    for i, r in enumerate(ref):
+        got = tr.get("params", i)
+        assert np.allclose(got, r, rtol=1e-6, atol=1e-9), "location %d" % i
+    tr.close()

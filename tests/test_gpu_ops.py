@@ -1,0 +1,200 @@
+"""Parity of every HIP kernel family against the CPU oracle, called through the C-ABI operator layer
+(mi_op_*).  Shapes are the reference-defined ResNet-50's own layer shapes at a
+small batch, plus config-1 shapes; the oracle works in NHWC (resnet.cu:145), the product in NCHW, so
+tensors are permuted on the way.  Tolerances: util.py (fp32, reduction order differs)."""
+import numpy as np
+import pytest
+
+from util import check_act, check_grad, nchw, nhwc, rand, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+# (C, H, K, k, stride, N)
+CONV_SHAPES = [
+    (3, 224, 64, 7, 2, 2),      # stem
+    (3, 32, 64, 7, 2, 4),       # stem, config 1
+    (64, 56, 64, 3, 1, 2),      # stage 0 spatial
+    (128, 56, 128, 3, 2, 2),    # b3 spatial (stride 2)
+    (256, 56, 512, 3, 2, 1),    # b3 projection 3x3 s2
+    (128, 28, 128, 3, 1, 3),
+    (256, 14, 256, 3, 1, 3),
+    (512, 14, 512, 3, 2, 2),    # b13 spatial
+    (512, 7, 512, 3, 1, 5),
+    (1024, 14, 2048, 3, 2, 1),  # b13 projection (18.9M weights)
+    (64, 8, 64, 3, 1, 4),       # config 1 block
+    (128, 8, 128, 3, 2, 4),     # config 1S strided block
+    (64, 56, 64, 1, 1, 2),      # 1x1 reduce (MFMA GEMM)
+    (64, 56, 256, 1, 1, 2),     # 1x1 expand / projection
+    (256, 56, 64, 1, 1, 2),
+    (1024, 14, 256, 1, 1, 3),
+    (512, 7, 2048, 1, 1, 5),    # P = 49: odd plane
+    (2048, 7, 512, 1, 1, 5),
+    (64, 8, 256, 1, 1, 4),      # config 1
+]
+IDS = ["C%d_H%d_K%d_k%d_s%d_N%d" % s for s in CONV_SHAPES]
+
+
+def _conv_data(C, H, K, k, stride, N, seed=7):
+    x = rand((N, H, H, C), seed)
+    w = rand((K, C, k, k), seed + 1, scale=(2.0 / (k * k * (C + K))) ** 0.5)
+    dy = rand((N, H // stride, H // stride, K), seed + 2)
+    return x, w, dy
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES, ids=IDS)
+def test_conv_fwd(ops, oracle, shape):
+    C, H, K, k, stride, N = shape
+    x, w, _ = _conv_data(*shape)
+    ref = oracle.conv_fwd(x, w, stride)
+    got = ops.conv_fwd(nchw(x), w, stride)
+    check_act(nhwc(got), ref, "conv_fwd %s" % (shape,))
+
+
+@pytest.mark.parametrize("shape", [s for s in CONV_SHAPES if s[0] != 3], ids=[i for s, i in zip(CONV_SHAPES, IDS) if s[0] != 3])
+def test_conv_dgrad(ops, oracle, shape):
+    C, H, K, k, stride, N = shape
+    x, w, dy = _conv_data(*shape)
+    ref = oracle.conv_dgrad(w, dy, H, stride)
+    got = ops.conv_dgrad(w, nchw(dy), H, stride)
+    check_grad(nhwc(got), ref, "conv_dgrad %s" % (shape,))
+    if k == 1:  # toAdd (residual join, resnet.cu:212-217)
+        base = rand((N, H, H, C), 99)
+        ref2 = oracle.conv_dgrad(w, dy, H, stride, dx_init=base)
+        got2 = ops.conv_dgrad(w, nchw(dy), H, stride, dx_init=nchw(base))
+        check_grad(nhwc(got2), ref2, "conv_dgrad+add %s" % (shape,))
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES, ids=IDS)
+def test_conv_wgrad(ops, oracle, shape):
+    C, H, K, k, stride, N = shape
+    x, w, dy = _conv_data(*shape)
+    ref = oracle.conv_wgrad(x, dy, k, stride)
+    got = ops.conv_wgrad(nchw(x), nchw(dy), k, stride)
+    check_grad(got, ref, "conv_wgrad %s" % (shape,))
+
+
+BN_SHAPES = [(64, 112, 2), (64, 56, 3), (256, 56, 2), (512, 28, 3), (1024, 14, 4), (2048, 7, 6), (512, 7, 5), (64, 8, 4), (256, 8, 4)]
+
+
+@pytest.mark.parametrize("C,H,N", BN_SHAPES)
+@pytest.mark.parametrize("relu", [0, 1])
+def test_bn_fwd_bwd(ops, oracle, C, H, N, relu):
+    eps = 1e-7
+    x = rand((N, H, H, C), 3, 2.0) + 0.5
+    gamma = (1 + 0.2 * rand((C,), 4)).astype(np.float32)
+    beta = (0.3 * rand((C,), 5)).astype(np.float32)
+    dy = rand((N, H, H, C), 6)
+    means, vars_, xhat, norm, act = oracle.bn_fwd(x, gamma, beta, eps, relu)
+    gm, gv, gy = ops.bn_fwd(nchw(x), gamma, beta, eps, relu)
+    check_act(gm, means, "bn means")
+    check_act(gv, vars_, "bn vars")
+    check_act(nhwc(gy), act, "bn out")
+    rdx, rdg, rdb = oracle.bn_bwd(x, gamma, eps, means, vars_, xhat, act, dy, relu)
+    # backward is fed the oracle's statistics: with the GPU's own (differently rounded) mean/var a handful of
+    # elements with |y| ~ 1e-7 flip their ReLU gate, which is a property of the comparison, not of the kernel
+    gdx, gdg, gdb = ops.bn_bwd(nchw(x), gamma, beta, means, vars_, nchw(dy), eps, 1 if relu else 0)
+    check_grad(nhwc(gdx), rdx, "bn dx")
+    check_grad(gdg, rdg, "bn dgamma")
+    check_grad(gdb, rdb, "bn dbeta")
+
+
+@pytest.mark.parametrize("C,H,N", [(256, 56, 2), (2048, 7, 5), (256, 8, 4)])
+def test_bn_add_relu_and_external_mask(ops, oracle, C, H, N):
+    """BN(expanded)+addVec+doActivation fused forward, and ReLU' fused into BN' as an external mask"""
+    eps = 1e-7
+    x = rand((N, H, H, C), 13)
+    res = rand((N, H, H, C), 14)
+    gamma = (1 + 0.2 * rand((C,), 15)).astype(np.float32)
+    beta = (0.3 * rand((C,), 16)).astype(np.float32)
+    up = rand((N, H, H, C), 17)
+    means, vars_, xhat, norm, act = oracle.bn_fwd(x, gamma, beta, eps, 0)
+    summ = act + res
+    out = np.maximum(summ, 0)
+    gm, gv, gy = ops.bn_fwd(nchw(x), gamma, beta, eps, 0, residual=nchw(res))
+    check_act(nhwc(gy), out, "bn+add+relu")
+    d_sum = np.where(summ > 0, up, 0).astype(np.float32)  # doActivationDeriv
+    rdx, rdg, rdb = oracle.bn_bwd(x, gamma, eps, means, vars_, xhat, act, d_sum, 0)
+    gdx, gdg, gdb = ops.bn_bwd(nchw(x), gamma, beta, gm, gv, nchw(up), eps, 2, mask_src=gy)
+    check_grad(nhwc(gdx), rdx, "bn dx (external mask)")
+    check_grad(gdg, rdg, "bn dgamma (external mask)")
+    check_grad(gdb, rdb, "bn dbeta (external mask)")
+    got = ops.relu_deriv(gy, nchw(up))
+    assert np.array_equal(nhwc(got), d_sum)
+
+
+@pytest.mark.parametrize("C,H,N", [(64, 112, 2), (64, 16, 4)])
+def test_maxpool(ops, oracle, C, H, N):
+    x = np.maximum(rand((N, H, H, C), 21), 0)  # post-ReLU input: ties at 0 exercise "first max wins"
+    y, idx = oracle.maxpool_fwd(x, 3, 2)
+    gy, gidx = ops.maxpool_fwd(nchw(x), 3, 2)
+    assert np.array_equal(nhwc(gy), y)
+    # the product stores flat NCHW indices, the oracle flat NHWC: compare the (ih, iw) they point at
+    Ho = H // 2
+    n_, c_ = np.arange(N)[:, None, None, None], np.arange(C)[None, :, None, None]
+    pos_g = gidx - (n_ * C + c_) * H * H
+    pos_r = (nchw(idx) - n_ * H * H * C - c_) // C
+    assert np.array_equal(pos_g, pos_r)
+    dy = rand((N, Ho, Ho, C), 22)
+    rdx = oracle.maxpool_bwd(idx, dy, H, 2)
+    gdx = ops.maxpool_bwd(gidx, nchw(dy), H, 3, 2)
+    assert np.array_equal(nhwc(gdx), rdx)  # overwrite scatter, last writer in scan order
+
+
+def test_avgpool(ops, oracle):
+    N, C, H = 5, 2048, 7
+    x = rand((N, H, H, C), 31)
+    ref = np.empty((N, C), np.float32)
+    oracle.lib.orc_avgpool_fwd(x, H, C, N, ref)
+    check_act(ops.avgpool_fwd(nchw(x)), ref, "avgpool")
+    dy = rand((N, C), 32)
+    rdx = np.empty((N, H, H, C), np.float32)
+    oracle.lib.orc_avgpool_bwd(dy, C, N, H, rdx)
+    check_act(nhwc(ops.avgpool_bwd(dy, H)), rdx, "avgpool bwd")
+
+
+def test_matmul_reference_selftest_shapes(ops, oracle):
+    """testMatMul / testTranspose of the reference (resnet.cu:2990-3107): 32x2048 . 2048x1000, data in +-1,
+    abs tolerance 1e-5 (:3081) -- here scaled by the result magnitude because operands are not the
+    reference's rand() stream."""
+    import synth
+    a = synth.uniform(41, 32 * 2048, -1, 1).reshape(32, 2048)
+    b = synth.uniform(42, 2048 * 1000, -1, 1).reshape(2048, 1000)
+    ref = oracle.matmul(a, b)
+    got = ops.matmul(a, b, "nn")
+    assert np.max(np.abs(got - ref)) <= 1e-5 * np.max(np.abs(ref)) * 10
+    # FC backward forms (prepareAndDoMatMulLeftTranspose / RightTranspose, resnet.cu:1482-1509)
+    d = synth.uniform(43, 32 * 1000, -1, 1).reshape(32, 1000)
+    ref_w = oracle.matmul(oracle.transpose(a), d)          # [2048 x 1000]
+    check_grad(ops.matmul(a, d, "lt"), ref_w, "fc wgrad")
+    ref_x = oracle.matmul(d, oracle.transpose(b))          # [32 x 2048]
+    check_grad(ops.matmul(d, b, "rt"), ref_x, "fc dgrad")
+
+
+def test_softmax_ce_adam(ops, oracle):
+    import synth
+    x = (synth.normal(51, 8 * 1000, 9.0)).reshape(8, 1000)
+    x[3, 17] = 95.0  # would overflow the reference's resnet.cu softmax (hazard h2); stable form required
+    ref = oracle.softmax(x)
+    got = ops.softmax(x)
+    check_act(got, ref, "softmax")
+    lab = synth.labels(52, 8, 1000)
+    d = ops.ce_deriv(got, lab)
+    refd = got.copy()
+    oracle.lib.orc_ce_deriv(refd, lab, 1000, 8)
+    assert np.array_equal(d, refd)
+    n = 10007
+    p, g = rand((n,), 61), rand((n,), 62, 0.01)
+    m, v = rand((n,), 63, 0.001), np.abs(rand((n,), 64, 1e-4))
+    g[5] = np.nan
+    g[6] = np.inf
+    rp, rm, rv = p.copy(), m.copy(), v.copy()
+    oracle.lib.orc_adam(n, rp, g, rm, rv, 1e-4, 1e-3, 0.9, 0.999, 0.9 ** 3, 0.999 ** 3, 1e-7)
+    gp, gm, gv, flag = ops.adam(p, g, m, v, 1e-4, 1e-3, 0.9, 0.999, 0.9 ** 3, 0.999 ** 3, 1e-7)
+    assert flag == 1  # NaN/Inf gradient seen (check_errors semantics, resnet.cu:2879-2907)
+    assert rel_l2(gp, rp) < 1e-6 and rel_l2(gm, rm) < 1e-6 and rel_l2(gv, rv) < 1e-6
+    assert gm[5] == m[5] and gv[6] == v[6]  # guards keep the old moments (resnet.cu:610-617)
+
+
+def test_layout(ops):
+    x = rand((3, 10, 10, 7), 71)
+    assert np.array_equal(ops.nhwc_to_nchw(x), nchw(x))
