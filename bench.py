@@ -32,7 +32,8 @@ def cpu_baseline(seconds_budget=30.0):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import synth
     from oracle.oracle_py import Oracle, OracleNet
-    cores = min(os.cpu_count() or 1, 64)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, 32)
     o = Oracle("f32")
     o.set_threads(cores)
     dims, batch = synth.R50_DIMS, 2
@@ -87,19 +88,10 @@ def main():
     dims = resnet_dims()
     tr = Trainer(dims, args.batch, lr=1e-4, wd=0.0, b1=0.9, b2=0.999, eps=1e-7, seed=1236, device=local_rank)
     # every rank draws its own slice of the global batch: distinct image/label streams per rank
-    tr.source_synthetic(1234 + 7919 * rank, 1235 + 7919 * rank, pool_batches=2)
+    from resnet_amd import dp
+    tr.source_synthetic(*dp.rank_seeds(rank), pool_batches=2)
     if world > 1:
-        import torch
-        nbytes = lib.mi_dp_unique_id_bytes()
-        uid = (C.c_char * nbytes)()
-        if rank == 0 and lib.mi_dp_get_unique_id(uid, nbytes) != 0:
-            raise SystemExit(tr.error())
-        t = torch.frombuffer(bytearray(uid.raw), dtype=torch.uint8).clone()
-        dist.broadcast(t, src=0)
-        raw = bytes(t.numpy().tobytes())
-        if lib.mi_dp_init(tr.t, rank, world, raw, nbytes) != 0:
-            raise SystemExit("mi_dp_init: " + tr.error())
-        lib.mi_dp_set_bucket_bytes(tr.t, args.bucket_mb << 20)
+        dp.init_data_parallel(tr, dist, rank, world, args.bucket_mb)
 
     def barrier():
         lib.mi_device_synchronize()
