@@ -298,6 +298,8 @@ int mi_op_ce_deriv(const float *pred, const int *labels, float *d, int N, int L)
 int mi_op_adam(float *p, const float *g, float *m, float *v, size_t n, float lr, float wd, float b1, float b2,
                float cur_b1, float cur_b2, float eps, int *nan_flag_dev);
 int mi_op_nhwc_to_nchw(const float *in, float *out, int N, int H, int W, int C);
+/* device-side seeded fill (splitmix64 counter stream, uniform [lo,hi)) -- synthetic operands for micro-benchmarks */
+int mi_op_fill_uniform(float *out, size_t n, uint64_t seed, float lo, float hi);
 
 #ifdef __cplusplus
 }

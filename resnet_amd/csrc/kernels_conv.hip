@@ -41,23 +41,26 @@ struct DConvArgs {
     int N, Cin, Hin, Win, Cout, Hof, Wof;
     int Hsub, Wsub, osy, oy0, osx, ox0; // output sub-grid: position (i*osy+oy0, j*osx+ox0)
     int sy, sx, offy, offx;             // input row of (i, tr) = i*sy + offy + tr
-    int PW, QR, Hq, CC, tbl_pad, lpr_log2;
+    int PW, QR, Hq, CC, tbl_pad, plane, jcnt;
     uint32_t total_pix;
-    FastDiv fd_Wsub, fd_Hsub, fd_Hq, fd_QR;
+    FastDiv fd_Wsub, fd_Hsub, fd_Hq, fd_PW;
 };
 
-template <int NTR, int NTC, int TK>
+// Pipeline per channel chunk (CC channels): the chunk after next is in flight from HBM/L2 into registers while the
+// current one is multiplied out of LDS buffer A and the next one sits in LDS buffer B -> ONE barrier per chunk and
+// no exposed global-load latency.  Each thread stages the same JM patch positions for every channel of a chunk.
+template <int NTR, int NTC, int TK, int JM, int CCM>
 __global__ void __launch_bounds__(448)
 dconv_kernel(const float *__restrict__ in, const float *__restrict__ wT, float *__restrict__ out,
              const float *__restrict__ addend, const DConvArgs a) {
     extern __shared__ float smem[];
     int *tbl = (int *)smem;
-    float *patch = smem + a.tbl_pad;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nw = blockDim.x >> 6;
+    float *patch0 = smem + a.tbl_pad;
+    const int tid = threadIdx.x;
     const uint32_t pix0 = blockIdx.x * blockDim.x;
     const int k0 = blockIdx.y * TK;
+    const int plane = a.plane, bufsz = a.CC * plane;
+    const int HW = a.Hin * a.Win;
 
     // first patch row of this workgroup in "q space" (q = n*Hq + i*sy + tr): contiguous for a pixel range
     const uint32_t R0 = fd_div(pix0, a.fd_Wsub);
@@ -78,37 +81,64 @@ dconv_kernel(const float *__restrict__ in, const float *__restrict__ wT, float *
     const uint32_t n = fd_div(R, a.fd_Hsub);
     const int i = (int)(R - n * a.Hsub);
     const int lbase = ((int)(n * a.Hq + i * a.sy) - q0) * a.PW + j * a.sx;
+    __syncthreads();
+    // patch positions this thread stages: pos = tid + 448*jj  ->  element offset inside channel 0 (or -1 = zero)
+    int goff[JM];
+#pragma unroll
+    for (int jj = 0; jj < JM; jj++) {
+        const int pos = tid + jj * 448;
+        int g = -1;
+        if (jj < a.jcnt && pos < plane) {
+            const uint32_t qr = fd_div((uint32_t)pos, a.fd_PW);
+            const int iw = pos - (int)qr * a.PW + a.offx;
+            const int t = tbl[qr];
+            if (t >= 0 && iw >= 0 && iw < a.Win) g = t + iw;
+        }
+        goff[jj] = g;
+    }
+    float regs[CCM][JM];
+    auto issue = [&](int c0) {
+#pragma unroll
+        for (int c = 0; c < CCM; c++) {
+            const bool cok = c < a.CC && c0 + c < a.Cin;
+            const float *src = in + (size_t)(c0 + c) * HW;
+#pragma unroll
+            for (int jj = 0; jj < JM; jj++) {
+                float v = 0.f;
+                if (cok && goff[jj] >= 0) v = src[goff[jj]];
+                regs[c][jj] = v;
+            }
+        }
+    };
+    auto stash = [&](float *buf) {
+#pragma unroll
+        for (int c = 0; c < CCM; c++) {
+            if (c < a.CC) {
+#pragma unroll
+                for (int jj = 0; jj < JM; jj++) {
+                    const int pos = tid + jj * 448;
+                    if (jj < a.jcnt && pos < plane) buf[c * plane + pos] = regs[c][jj];
+                }
+            }
+        }
+    };
 
     float acc[TK];
 #pragma unroll
     for (int t = 0; t < TK; t++) acc[t] = 0.f;
 
-    const int plane = a.QR * a.PW;
-    const int HW = a.Hin * a.Win;
-    const int lpr = 1 << a.lpr_log2, rpi = 64 >> a.lpr_log2;
-    const int lr = lane >> a.lpr_log2, lc = lane & (lpr - 1);
-
-    for (int c0 = 0; c0 < a.Cin; c0 += a.CC) {
+    const int nch = (a.Cin + a.CC - 1) / a.CC;
+    issue(0);
+    stash(patch0);
+    if (nch > 1) issue(a.CC);
+    __syncthreads();
+    for (int ch = 0; ch < nch; ch++) {
+        const float *cur = patch0 + (ch & 1) * bufsz;
+        const int c0 = ch * a.CC;
         const int cc = min(a.CC, a.Cin - c0);
-        __syncthreads();
-        const int rows = cc * a.QR;
-        for (int rr = wave * rpi + lr; rr < rows; rr += nw * rpi) {
-            const uint32_t c = fd_div((uint32_t)rr, a.fd_QR);
-            const int qr = rr - (int)c * a.QR;
-            const int off = tbl[qr];
-            const float *src = in + (size_t)(c0 + c) * HW + (off < 0 ? 0 : off);
-            float *dst = patch + c * plane + qr * a.PW;
-            for (int col = lc; col < a.PW; col += lpr) {
-                const int iw = col + a.offx;
-                float v = 0.f;
-                if (off >= 0 && iw >= 0 && iw < a.Win) v = src[iw];
-                dst[col] = v;
-            }
-        }
-        __syncthreads();
         for (int c = 0; c < cc; c++) {
             const float *wp = wT + (size_t)(c0 + c) * (NTR * NTC) * a.Cout + k0; // wave-uniform -> scalar loads
-            const float *pp = patch + c * plane + lbase;
+            const float *pp = cur + c * plane + lbase;
 #pragma unroll
             for (int tr = 0; tr < NTR; tr++) {
 #pragma unroll
@@ -120,6 +150,11 @@ dconv_kernel(const float *__restrict__ in, const float *__restrict__ wT, float *
                 }
             }
         }
+        if (ch + 1 < nch) {
+            stash(patch0 + ((ch + 1) & 1) * bufsz);
+            if (ch + 2 < nch) issue(c0 + 2 * a.CC);
+        }
+        __syncthreads();
     }
     if (pvalid) {
         const int oh = i * a.osy + a.oy0, ow = j * a.osx + a.ox0;
@@ -135,7 +170,17 @@ dconv_kernel(const float *__restrict__ in, const float *__restrict__ wT, float *
     }
 }
 
-static int ilog2_ceil(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
+template <int NTR, int NTC>
+static int launch_dconv_t(hipStream_t st, dim3 grid, size_t lds, int tk, int jm, const float *in, const float *wT, float *out,
+                          const float *addend, const DConvArgs &a) {
+    dim3 block(448);
+#define DCL(TK_, JM_, CCM_) hipLaunchKernelGGL((dconv_kernel<NTR, NTC, TK_, JM_, CCM_>), grid, block, lds, st, in, wT, out, addend, a)
+    if (jm <= 2) { if (tk == 32) DCL(32, 2, 8); else DCL(16, 2, 8); }
+    else if (jm <= 5) { if (tk == 32) DCL(32, 5, 3); else DCL(16, 5, 3); }
+    else { if (tk == 32) DCL(32, 7, 3); else DCL(16, 7, 3); }
+#undef DCL
+    return 0;
+}
 
 // one tap-kernel launch; ntr x ntc taps, weights already re-laid in wT
 static int launch_dconv(hipStream_t st, const float *in, const float *wT, float *out, const float *addend, DConvArgs a,
@@ -152,37 +197,35 @@ static int launch_dconv(hipStream_t st, const float *in, const float *wT, float 
     if (PIX % a.Wsub == 0 && (a.Hsub % rb == 0)) nimg = 1;
     a.QR = (int)((rb - 1) * a.sy + ntr + (nimg - 1) * (ntr > a.sy ? ntr - a.sy : 0));
     a.tbl_pad = (a.QR + 3) & ~3;
-    int cc = 10240 / (a.QR * a.PW);
+    a.plane = a.QR * a.PW;
+    a.jcnt = (a.plane + PIX - 1) / PIX;
+    if (a.jcnt > 7) { mi_record_error("dconv", "input patch too large for this shape"); return -2; }
+    const int ccm = a.jcnt <= 2 ? 8 : 3;
+    int cc = 5120 / a.plane; // two LDS buffers of <= 20 KB each
     if (cc < 1) cc = 1;
-    if (cc > 16) cc = 16;
+    if (cc > ccm) cc = ccm;
     if (cc > a.Cin) cc = a.Cin;
     a.CC = cc;
-    const size_t lds = (size_t)(a.tbl_pad + (size_t)cc * a.QR * a.PW) * 4;
+    const size_t lds = (size_t)(a.tbl_pad + 2 * (size_t)cc * a.plane) * 4;
     if (lds > 64 * 1024) { mi_record_error("dconv", "LDS patch too large for this shape"); return -2; }
-    int l = ilog2_ceil(a.PW);
-    a.lpr_log2 = l > 6 ? 6 : l;
     a.fd_Wsub = make_fastdiv(a.Wsub); a.fd_Hsub = make_fastdiv(a.Hsub);
-    a.fd_Hq = make_fastdiv(a.Hq); a.fd_QR = make_fastdiv(a.QR);
+    a.fd_Hq = make_fastdiv(a.Hq); a.fd_PW = make_fastdiv(a.PW);
     const int tk = (a.Cout % 32 == 0) ? 32 : 16;
     if (a.Cout % 16 != 0) { mi_record_error("dconv", "channel count must be a multiple of 16"); return -2; }
-    dim3 grid(mi_cdiv(a.total_pix, PIX), a.Cout / tk), block(PIX);
+    dim3 grid(mi_cdiv(a.total_pix, PIX), a.Cout / tk);
     // algorithmic work of this launch: 2*taps MACs per (pixel, cin, cout); bytes = input + weights + output once
     const double fl = 2.0 * ntr * ntc * (double)a.total_pix * a.Cin * a.Cout;
     const double by = 4.0 * ((double)a.N * a.Cin * a.Hin * a.Win / (a.osy * a.osx) + (double)ntr * ntc * a.Cin * a.Cout +
                              (double)a.total_pix * a.Cout * (addend ? 2 : 1));
     mi_prof_begin(st, MI_FAM_DCONV, fl, by);
-#define DC(NTR_, NTC_)                                                                                             \
-    if (ntr == NTR_ && ntc == NTC_) {                                                                              \
-        if (tk == 32) hipLaunchKernelGGL((dconv_kernel<NTR_, NTC_, 32>), grid, block, lds, st, in, wT, out, addend, a); \
-        else hipLaunchKernelGGL((dconv_kernel<NTR_, NTC_, 16>), grid, block, lds, st, in, wT, out, addend, a);      \
-        mi_prof_end(st);                                                                                           \
-        MI_LAUNCH_CHECK("dconv_kernel");                                                                           \
-        return 0;                                                                                                  \
-    }
+    int rc = -2;
+#define DC(NTR_, NTC_) if (ntr == NTR_ && ntc == NTC_) rc = launch_dconv_t<NTR_, NTC_>(st, grid, lds, tk, a.jcnt, in, wT, out, addend, a);
     DC(3, 3) DC(7, 7) DC(1, 1) DC(1, 2) DC(2, 1) DC(2, 2)
 #undef DC
-    mi_record_error("dconv", "unsupported tap shape");
-    return -2;
+    mi_prof_end(st);
+    if (rc) { mi_record_error("dconv", "unsupported tap shape"); return rc; }
+    MI_LAUNCH_CHECK("dconv_kernel");
+    return 0;
 }
 
 static int launch_wt(hipStream_t st, const float *w, float *out, int Ci, int Co, int T, int k, int C, int transposed,

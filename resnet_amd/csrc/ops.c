@@ -85,3 +85,4 @@ int mi_op_adam(float *p, const float *g, float *m, float *v, size_t n, float lr,
     return finish(mid_adam(mi_global()->compute, p, g, m, v, n, lr, wd, b1, b2, cur_b1, cur_b2, eps, nan_flag_dev));
 }
 int mi_op_nhwc_to_nchw(const float *in, float *out, int N, int H, int W, int C) { return finish(mid_nhwc_to_nchw(mi_global()->compute, in, out, N, H, W, C)); }
+int mi_op_fill_uniform(float *out, size_t n, uint64_t seed, float lo, float hi) { return finish(mid_fill_uniform(mi_global()->compute, out, n, seed, 0, lo, hi)); }

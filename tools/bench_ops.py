@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Per-layer micro-benchmark of the conv kernel families through the C-ABI operator layer, on the reference
+network's own layer shapes.  Operands are device-generated uniform random data (zero
+operands would inflate clocks); timing is the library's HIP-event bracket around each kernel launch.
+  python tools/bench_ops.py [--batch 256] [--reps 3] [--only fwd,dgrad,wgrad] [--filter 3x3]"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from resnet_amd import binding as B  # noqa: E402
+
+# (name, C, H, K, k, stride, count per step)
+LAYERS = [
+    ("stem7x7", 3, 224, 64, 7, 2, 1),
+    ("s0_3x3", 64, 56, 64, 3, 1, 3),
+    ("b3_3x3s2", 128, 56, 128, 3, 2, 1),
+    ("b3_proj", 256, 56, 512, 3, 2, 1),
+    ("s1_3x3", 128, 28, 128, 3, 1, 3),
+    ("b7_3x3s2", 256, 28, 256, 3, 2, 1),
+    ("b7_proj", 512, 28, 1024, 3, 2, 1),
+    ("s2_3x3", 256, 14, 256, 3, 1, 5),
+    ("b13_3x3s2", 512, 14, 512, 3, 2, 1),
+    ("b13_proj", 1024, 14, 2048, 3, 2, 1),
+    ("s3_3x3", 512, 7, 512, 3, 1, 2),
+    ("1x1_64_256@56", 64, 56, 256, 1, 1, 4),
+    ("1x1_256_64@56", 256, 56, 64, 1, 1, 2),
+    ("1x1_512_128@28", 512, 28, 128, 1, 1, 3),
+    ("1x1_128_512@28", 128, 28, 512, 1, 1, 4),
+    ("1x1_1024_256@14", 1024, 14, 256, 1, 1, 5),
+    ("1x1_256_1024@14", 256, 14, 1024, 1, 1, 6),
+    ("1x1_2048_512@7", 2048, 7, 512, 1, 1, 2),
+    ("1x1_512_2048@7", 512, 7, 2048, 1, 1, 3),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--only", default="fwd,dgrad,wgrad")
+    ap.add_argument("--filter", default="")
+    args = ap.parse_args()
+    L = B.load()
+    if L.mi_device_count() < 1:
+        raise SystemExit("needs a HIP device")
+    N = args.batch
+    tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
+    print("%-18s %-6s %9s %9s" % ("layer", "op", "ms", "TFLOP/s"))
+    for name, Cc, H, K, k, s, cnt in LAYERS:
+        if args.filter and args.filter not in name:
+            continue
+        Ho = H // s
+        nx, nw, ny = N * Cc * H * H, K * Cc * k * k, N * K * Ho * Ho
+        x, w, y, dx, dw = (L.mi_malloc(4 * n) for n in (nx, nw, ny, nx, nw))
+        L.mi_op_fill_uniform(x, nx, 1, -1.0, 1.0)
+        L.mi_op_fill_uniform(w, nw, 2, -0.1, 0.1)
+        L.mi_op_fill_uniform(y, ny, 3, -1.0, 1.0)
+        flops = 2.0 * k * k * N * Ho * Ho * Cc * K
+        for op in args.only.split(","):
+            if op == "dgrad" and Cc == 3:
+                continue
+            L.mi_prof_enable(1)
+            for rep in range(args.reps + 1):
+                if rep == 1:
+                    L.mi_prof_reset()
+                if op == "fwd":
+                    rc = L.mi_op_conv_fwd(x, w, y, N, Cc, H, K, k, s)
+                elif op == "dgrad":
+                    rc = L.mi_op_conv_dgrad(w, y, dx, N, Cc, H, K, k, s, 0)
+                else:
+                    rc = L.mi_op_conv_wgrad(x, y, dw, N, Cc, H, K, k, s)
+                if rc != 0:
+                    raise SystemExit("%s %s failed: %s" % (name, op, L.mi_last_error().decode()))
+            ms = 0.0
+            for fam in (0, 1, 2):
+                n_, ms_, fl_, by_ = C.c_long(0), C.c_double(0), C.c_double(0), C.c_double(0)
+                L.mi_prof_get(fam, C.byref(n_), C.byref(ms_), C.byref(fl_), C.byref(by_))
+                ms += ms_.value
+            L.mi_prof_enable(0)
+            ms /= args.reps
+            tot[op] += ms * cnt
+            print("%-18s %-6s %9.3f %9.1f" % (name, op, ms, flops / ms / 1e9))
+        for p in (x, w, y, dx, dw):
+            L.mi_free(p)
+    print("per-step totals (ms, weighted by layer count):", {k_: round(v, 1) for k_, v in tot.items()})
+
+
+if __name__ == "__main__":
+    main()
