@@ -252,11 +252,14 @@ struct WgArgs {
 };
 #define WG_LDP 65
 
+// Pipeline: while chunk ch is multiplied (dY tile in LDS buffer ch&1, x rows in registers), chunk ch+1 is in flight
+// from memory into registers -> one barrier per chunk.  Pixels are walked four at a time so that one v_readlane
+// window of 3*S+KS input elements serves 4*KS taps (rolling reuse along the row).
 template <int KS, int S, int TKL, int TC, int NXR>
 __global__ void __launch_bounds__(256)
 wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ part, const WgArgs a) {
-    constexpr int KT = 64 * TKL, T = KS * KS, RPCMAX = (NXR - KS) / S + 1;
-    extern __shared__ float dyS[]; // [KT][WG_LDP]
+    constexpr int KT = 64 * TKL, T = KS * KS, RPCMAX = (NXR - KS) / S + 1, DYR = KT / 4, NXS = 3 * S + KS;
+    extern __shared__ float dyS[]; // [2][KT][WG_LDP]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kb = blockIdx.x * KT;
@@ -271,56 +274,88 @@ wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *_
 
     const int ch_beg = blockIdx.z * a.chunks_per_split;
     const int ch_end = min(a.chunks_total, ch_beg + a.chunks_per_split);
-    for (int ch = ch_beg; ch < ch_end; ch++) {
+    float dreg[DYR], xnext[TC][NXR], xrow[TC][NXR];
+
+    struct Geo { int n, oh0, rows, ow0, segw; };
+    auto geom = [&](int ch) {
+        Geo g;
         const uint32_t t1 = fd_div((uint32_t)ch, a.fd_SG);
         const int sg = ch - (int)t1 * a.SG;
         const uint32_t n = fd_div(t1, a.fd_RG);
         const int rg = (int)(t1 - n * a.RG);
-        const int oh0 = rg * a.RPC, rows = min(a.RPC, a.Ho - oh0);
-        const int ow0 = sg * a.SEGW, segw = min(a.SEGW, a.Wo - ow0);
-        const int npx = rows * segw; // rows==1 or segw==Wo: pixels of a k-plane are one contiguous run
-        __syncthreads();
-        for (int kk = wave; kk < KT; kk += 4) {
-            const float *src = dy + (((size_t)n * a.K + kb + kk) * a.Ho + oh0) * a.Wo + ow0;
-            for (int px = lane; px < npx; px += 64) dyS[kk * WG_LDP + px] = src[px];
+        g.n = (int)n; g.oh0 = rg * a.RPC; g.rows = min(a.RPC, a.Ho - g.oh0);
+        g.ow0 = sg * a.SEGW; g.segw = min(a.SEGW, a.Wo - g.ow0);
+        return g;
+    };
+    auto issue = [&](int ch) {
+        const Geo g = geom(ch);
+        const int npx = g.rows * g.segw; // rows==1 or segw==Wo: pixels of a k-plane are one contiguous run
+#pragma unroll
+        for (int q = 0; q < DYR; q++) {
+            const int kk = wave + 4 * q;
+            float v = 0.f;
+            if (lane < npx) v = dy[(((size_t)g.n * a.K + kb + kk) * a.Ho + g.oh0) * a.Wo + g.ow0 + lane];
+            dreg[q] = v;
         }
-        // input row segments, one element per lane
-        float xrow[TC][NXR];
-        const int nxr = (rows - 1) * S + KS;
-        const int iw = ow0 * S - a.pad + lane;
-        const bool colok = iw >= 0 && iw < a.W && lane < (segw - 1) * S + KS;
+        const int nxr = (g.rows - 1) * S + KS;
+        const int iw = g.ow0 * S - a.pad + lane;
+        const bool colok = iw >= 0 && iw < a.W && lane < (g.segw - 1) * S + KS;
 #pragma unroll
         for (int c = 0; c < TC; c++) {
             const int cch = cb + c;
 #pragma unroll
             for (int xr = 0; xr < NXR; xr++) {
-                const int ih = oh0 * S - a.pad + xr;
+                const int ih = g.oh0 * S - a.pad + xr;
                 float v = 0.f;
                 if (xr < nxr && cch < a.C && ih >= 0 && ih < a.H && colok)
-                    v = x[(((size_t)n * a.C + cch) * a.H + ih) * a.W + iw];
-                xrow[c][xr] = v;
+                    v = x[(((size_t)g.n * a.C + cch) * a.H + ih) * a.W + iw];
+                xnext[c][xr] = v;
             }
         }
+    };
+
+    if (ch_beg < ch_end) issue(ch_beg);
+    for (int ch = ch_beg; ch < ch_end; ch++) {
+        float *buf = dyS + ((ch - ch_beg) & 1) * (KT * WG_LDP);
+#pragma unroll
+        for (int q = 0; q < DYR; q++) buf[(wave + 4 * q) * WG_LDP + lane] = dreg[q];
+#pragma unroll
+        for (int c = 0; c < TC; c++)
+#pragma unroll
+            for (int xr = 0; xr < NXR; xr++) xrow[c][xr] = xnext[c][xr];
+        const Geo g = geom(ch);
+        if (ch + 1 < ch_end) issue(ch + 1);
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < RPCMAX; r++) {
-            if (r < rows) {
-                for (int ow = 0; ow < segw; ow++) {
-                    float d[TKL];
+            if (r < g.rows) {
+                for (int ow4 = 0; ow4 < g.segw; ow4 += 4) {
+                    float d[TKL][4];
 #pragma unroll
-                    for (int u = 0; u < TKL; u++) d[u] = dyS[(lane + 64 * u) * WG_LDP + r * segw + ow];
+                    for (int q4 = 0; q4 < 4; q4++) {
+                        const bool ok = ow4 + q4 < g.segw; // tail pixels contribute 0
+#pragma unroll
+                        for (int u = 0; u < TKL; u++) {
+                            const float v = buf[(lane + 64 * u) * WG_LDP + r * g.segw + ow4 + q4];
+                            d[u][q4] = ok ? v : 0.f;
+                        }
+                    }
 #pragma unroll
                     for (int c = 0; c < TC; c++)
 #pragma unroll
-                        for (int tr = 0; tr < KS; tr++)
+                        for (int tr = 0; tr < KS; tr++) {
+                            float xs[NXS];
 #pragma unroll
-                            for (int tc = 0; tc < KS; tc++) {
-                                const float xs = __int_as_float(
-                                    __builtin_amdgcn_readlane(__float_as_int(xrow[c][r * S + tr]), ow * S + tc));
+                            for (int m = 0; m < NXS; m++)
+                                xs[m] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xrow[c][r * S + tr]), (ow4 * S + m) & 63));
 #pragma unroll
-                                for (int u = 0; u < TKL; u++)
-                                    acc[u][c][tr * KS + tc] = fmaf(xs, d[u], acc[u][c][tr * KS + tc]);
-                            }
+                            for (int q4 = 0; q4 < 4; q4++)
+#pragma unroll
+                                for (int tc = 0; tc < KS; tc++)
+#pragma unroll
+                                    for (int u = 0; u < TKL; u++)
+                                        acc[u][c][tr * KS + tc] = fmaf(xs[q4 * S + tc], d[u][q4], acc[u][c][tr * KS + tc]);
+                        }
                 }
             }
         }
@@ -338,6 +373,175 @@ wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *_
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// wgrad, 3x3 with C % 64 == 0 ("C" formulation; the read-lane kernel above remains for the 7x7 stem).
+// Lane = input channel c (64 per workgroup), wave = 8 output channels (32 per workgroup), 72 accumulators per lane.
+// Per chunk of output pixels both operands go through LDS: the x patch channel-major with an odd pitch (lane c reads
+// its own row, conflict-free) and the dY tile [k][pixel] read as broadcast ds_read_b128 (four pixels of one k).
+// Pixels are walked four at a time with a rolling x window (3 rows x (3*S+3) columns serve 4 pixels x 9 taps);
+// rows are padded to whole quads with zero dY.  Global loads of the NEXT chunk are in flight in registers.
+// (A scalar-load variant of the dY operand was measured first: correct but latency-bound on cold scalar-cache
+// misses, 19-38 TF; unlike dconv's weights the dY stream is unique per workgroup.)
+struct WcArgs {
+    int N, C, H, W, K, Ho, Wo, pad;
+    int NPX, rows, segw, QPR, DP, cpp, chunks_total, chunks_per_split;
+    int PR, PW, cwlog2, pitch, jcnt, xs_floats;
+    FastDiv fd_cpp, fd_Wo, fd_PR, fd_Q4;
+    size_t part_stride;
+};
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define WC_DPK 36 /* dY tile: [pixel slot][32 k] padded to 36 floats (16-B aligned rows) */
+
+template <int S>
+__global__ void __launch_bounds__(256)
+wgradC_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ part, const WcArgs a) {
+    constexpr int JM = 24, NXW = 3 * S + 3;
+    extern __shared__ float sm[];
+    float *xsm = sm;                 // [64][pitch] + slack
+    float *dys = sm + a.xs_floats;   // [32][DP]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kb0 = blockIdx.x * 32, cb = blockIdx.y * 64;
+    const int rpi = 64 >> a.cwlog2, col = lane & ((1 << a.cwlog2) - 1), sub = lane >> a.cwlog2;
+    const int npairs = 64 * a.PR, plane_o = a.Ho * a.Wo;
+    // accumulators as k-pairs: v_pk_fma_f32 takes (dY[k], dY[k+1]) straight out of a ds_read_b128 and the x value
+    // as a broadcast half -- no register shuffling to feed the packed FMA
+    f32x2 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int kp = 0; kp < 4; kp++) acc[t][kp] = (f32x2){0.f, 0.f};
+    for (int i = tid; i < 16; i += 256) xsm[64 * a.pitch + i] = 0.f; // slack read by masked tail columns
+    float pre[JM], pred[4];
+    // dY tile slot of this thread: the same (row, column) for its 4 k-rows
+    const int ps = tid & 31;
+    const uint32_t dr = fd_div((uint32_t)ps, a.fd_Q4);
+    const int dq = ps - (int)dr * (a.QPR * 4);
+    const bool dslot = ps < a.rows * a.QPR * 4;
+
+    auto issue = [&](int ch, int z) {
+        const uint32_t n = fd_div((uint32_t)ch, a.fd_cpp);
+        const int p0 = (ch - (int)n * a.cpp) * a.NPX;
+        const int npx = min(a.NPX, plane_o - p0);
+        const uint32_t oh0 = fd_div((uint32_t)p0, a.fd_Wo);
+        const int ih0 = (int)oh0 * S - a.pad, iw = (p0 - (int)oh0 * a.Wo) * S - a.pad + col;
+        const bool colok = col < a.PW && iw >= 0 && iw < a.W;
+#pragma unroll
+        for (int j = 0; j < JM; j++) {
+            const int pi = (wave + 4 * j) * rpi + sub + z; // z: opaque 0, keeps this arithmetic out of registers
+            float v = 0.f;
+            if (j < a.jcnt && pi < npairs && colok) {
+                const uint32_t c = fd_div((uint32_t)pi, a.fd_PR);
+                const int ih = ih0 + pi - (int)c * a.PR;
+                if (ih >= 0 && ih < a.H) v = x[(((size_t)n * a.C + cb + c) * a.H + ih) * a.W + iw];
+            }
+            pre[j] = v;
+        }
+        const int pix = (int)dr * a.segw + dq;
+        const bool dok = dslot && dq < a.segw && pix < npx;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int kk = (tid >> 5) + 8 * j;
+            float v = 0.f;
+            if (dok) v = dy[((size_t)n * a.K + kb0 + kk) * plane_o + p0 + pix];
+            pred[j] = v;
+        }
+    };
+    auto stash = [&](int z) {
+#pragma unroll
+        for (int j = 0; j < JM; j++) {
+            const int pi = (wave + 4 * j) * rpi + sub + z;
+            if (j < a.jcnt && pi < npairs && col < a.PW) {
+                const uint32_t c = fd_div((uint32_t)pi, a.fd_PR);
+                xsm[c * a.pitch + (pi - (int)c * a.PR) * a.PW + col] = pre[j];
+            }
+        }
+        if (dslot) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) dys[ps * WC_DPK + (tid >> 5) + 8 * j] = pred[j];
+        }
+    };
+
+    const int ch_beg = blockIdx.z * a.chunks_per_split;
+    const int ch_end = min(a.chunks_total, ch_beg + a.chunks_per_split);
+    int z = 0;
+    if (ch_beg < ch_end) issue(ch_beg, 0);
+    const float *xl = xsm + lane * a.pitch;
+    const float *dw = dys + wave * 8;
+    for (int ch = ch_beg; ch < ch_end; ch++) {
+        asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+        __syncthreads();
+        stash(z);
+        __syncthreads();
+        if (ch + 1 < ch_end) issue(ch + 1, z);
+        for (int r = 0; r < a.rows; r++) {
+            for (int q = 0; q < a.QPR; q++) {
+                float xw[3][NXW];
+                const float *xb = xl + r * S * a.PW + q * 4 * S;
+#pragma unroll
+                for (int tr = 0; tr < 3; tr++)
+#pragma unroll
+                    for (int m = 0; m < NXW; m++) xw[tr][m] = xb[tr * a.PW + m];
+                const float *db = dw + (r * a.QPR + q) * 4 * WC_DPK;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const f32x4 da = *(const f32x4 *)(db + j * WC_DPK), dbv = *(const f32x4 *)(db + j * WC_DPK + 4);
+                    const f32x2 d2[4] = {(f32x2){da[0], da[1]}, (f32x2){da[2], da[3]}, (f32x2){dbv[0], dbv[1]}, (f32x2){dbv[2], dbv[3]}};
+#pragma unroll
+                    for (int tr = 0; tr < 3; tr++)
+#pragma unroll
+                        for (int tc = 0; tc < 3; tc++) {
+                            const float xv = xw[tr][j * S + tc];
+                            const f32x2 x2 = (f32x2){xv, xv};
+#pragma unroll
+                            for (int kp = 0; kp < 4; kp++)
+                                acc[tr * 3 + tc][kp] = __builtin_elementwise_fma(d2[kp], x2, acc[tr * 3 + tc][kp]);
+                        }
+                }
+            }
+        }
+    }
+    float *po = part + (size_t)blockIdx.z * a.part_stride;
+    const int kb = kb0 + wave * 8;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+#pragma unroll
+        for (int t = 0; t < 9; t++) po[((size_t)(kb + k) * a.C + cb + lane) * 9 + t] = acc[t][k >> 1][k & 1];
+}
+
+int mi_launch_split_reduce(hipStream_t st, const float *part, float *out, long n, int splits, size_t stride);
+struct WbPlan { int npx, rows, segw, qpr, cpp, chunks, splits, cps, PR, PW, cwlog2, pitch, jcnt; };
+static int wgradB_plan(int N, int C, int H, int K, int k, int stride, WbPlan *p) {
+    if (k != 3 || (stride != 1 && stride != 2) || C % 64 || K % 32 || H % stride) return -1;
+    const int Wo = H / stride, npxmax = stride == 1 ? 28 : 14;
+    int npx = 0;
+    if (Wo >= npxmax) { for (int d = npxmax; d >= 4; d--) if (Wo % d == 0) { npx = d; break; } }
+    else npx = Wo * (npxmax / Wo);
+    if (npx < 4) return -1;
+    p->rows = npx >= Wo ? npx / Wo : 1;
+    p->segw = npx >= Wo ? Wo : npx;
+    p->qpr = mi_cdiv(p->segw, 4);
+    if (p->rows * p->qpr * 4 > 32) return -1;
+    p->npx = npx;
+    p->PR = (p->rows - 1) * stride + 3;
+    p->PW = (p->segw - 1) * stride + 3;
+    if (p->PW > 32) return -1;
+    p->cwlog2 = p->PW > 16 ? 5 : 4;
+    p->pitch = (p->PR * p->PW) | 1;
+    p->jcnt = mi_cdiv(64 * p->PR, 4 * (64 >> p->cwlog2));
+    if (p->jcnt > 24) return -1;
+    p->cpp = mi_cdiv(Wo * Wo, npx);
+    p->chunks = N * p->cpp;
+    const int base_blocks = (K / 32) * (C / 64);
+    int splits = mi_cdiv(2048, base_blocks);
+    if (splits > p->chunks) splits = p->chunks;
+    if (splits < 1) splits = 1;
+    p->cps = mi_cdiv(p->chunks, splits);
+    p->splits = mi_cdiv(p->chunks, p->cps);
+    return 0;
 }
 
 __global__ void split_reduce_kernel(const float *__restrict__ part, float *__restrict__ out, long n, int splits,
@@ -362,9 +566,9 @@ static int wgrad_plan(int N, int C, int H, int K, int k, int stride, WgPlan *p) 
     if (!((k == 3 && (stride == 1 || stride == 2)) || (k == 7 && stride == 2))) return -1;
     if (K % 64 != 0) return -1;
     const int Ho = H / stride, Wo = Ho;
-    const int rpcmax = (k == 7) ? 1 : 7;
+    const int rpcmax = (k == 7) ? 1 : (stride == 2 ? 4 : 7); /* NXR = 9 input rows held per channel */
     p->tkl = (k == 7) ? 1 : (K >= 128 ? 2 : 1);
-    p->tc = (k == 7) ? 1 : (stride == 2 ? 1 : 2);
+    p->tc = (k == 7) ? 1 : 2;
     int segmax = (64 - k) / stride + 1; // (segw-1)*stride + k <= 64
     if (segmax > 64) segmax = 64;
     if (Wo <= segmax) { p->segw = Wo; p->sg = 1; }
@@ -384,7 +588,7 @@ static int wgrad_plan(int N, int C, int H, int K, int k, int stride, WgPlan *p) 
 
 template <int KS, int S, int TKL, int TC, int NXR>
 static int launch_wgrad_t(hipStream_t st, const float *x, const float *dy, float *part, const WgArgs &a, dim3 grid) {
-    const size_t lds = (size_t)64 * TKL * WG_LDP * 4;
+    const size_t lds = (size_t)2 * 64 * TKL * WG_LDP * 4;
     mi_prof_begin(st, MI_FAM_WGRAD, 2.0 * KS * KS * (double)a.N * a.Ho * a.Wo * a.C * a.K,
                   4.0 * ((double)a.N * a.C * a.H * a.W + (double)a.N * a.K * a.Ho * a.Wo + (double)KS * KS * a.C * a.K));
     hipLaunchKernelGGL((wgrad_kernel<KS, S, TKL, TC, NXR>), grid, dim3(256), lds, st, x, dy, part, a);
@@ -408,6 +612,8 @@ size_t mid_conv_ws_wt_floats(int C, int K, int k) { return k == 1 ? 0 : (size_t)
 
 size_t mid_conv_ws_part_floats(int N, int C, int H, int K, int k, int stride) {
     if (k == 1) return mi_conv1x1_wgrad_part_floats(N, C, H * H, K);
+    WbPlan pb;
+    if (!wgradB_plan(N, C, H, K, k, stride, &pb)) return pb.splits > 1 ? (size_t)pb.splits * K * C * 9 : 0;
     WgPlan p;
     if (wgrad_plan(N, C, H, K, k, stride, &p)) return 0;
     return (size_t)p.splits * K * C * k * k;
@@ -473,6 +679,31 @@ int mid_conv_wgrad(mid_stream s, mid_workspace *ws, const float *x, const float 
                    int K, int k, int stride) {
     hipStream_t st = (hipStream_t)s;
     if (k == 1 && stride == 1) return mi_conv1x1_wgrad(st, ws, x, dy, dw, N, C, H * H, K);
+    WbPlan pb;
+    if (!wgradB_plan(N, C, H, K, k, stride, &pb)) {
+        const size_t wsz9 = (size_t)K * C * 9;
+        if (pb.splits > 1 && (!ws || ws->part_floats < wsz9 * pb.splits)) { mi_record_error("mid_conv_wgrad", "workspace too small"); return -3; }
+        WcArgs b;
+        b.N = N; b.C = C; b.H = H; b.W = H; b.K = K; b.Ho = H / stride; b.Wo = H / stride; b.pad = 1;
+        b.NPX = pb.npx; b.rows = pb.rows; b.segw = pb.segw; b.QPR = pb.qpr; b.DP = pb.rows * pb.qpr * 4;
+        b.cpp = pb.cpp; b.chunks_total = pb.chunks; b.chunks_per_split = pb.cps;
+        b.PR = pb.PR; b.PW = pb.PW; b.cwlog2 = pb.cwlog2; b.pitch = pb.pitch; b.jcnt = pb.jcnt;
+        b.xs_floats = (64 * pb.pitch + 16 + 3) & ~3;
+        b.fd_cpp = make_fastdiv(pb.cpp); b.fd_Wo = make_fastdiv(b.Wo); b.fd_PR = make_fastdiv(pb.PR);
+        b.fd_Q4 = make_fastdiv(pb.qpr * 4);
+        b.part_stride = wsz9;
+        float *outp = pb.splits == 1 ? dw : ws->part;
+        dim3 grid(K / 32, C / 64, pb.splits);
+        const size_t lds = (size_t)(b.xs_floats + 32 * WC_DPK) * 4;
+        mi_prof_begin(st, MI_FAM_WGRAD, 2.0 * 9 * (double)N * b.Ho * b.Wo * C * K,
+                      4.0 * ((double)N * C * H * H + (double)N * K * b.Ho * b.Wo + 9.0 * C * K));
+        if (stride == 1) hipLaunchKernelGGL((wgradC_kernel<1>), grid, dim3(256), lds, st, x, dy, outp, b);
+        else hipLaunchKernelGGL((wgradC_kernel<2>), grid, dim3(256), lds, st, x, dy, outp, b);
+        mi_prof_end(st);
+        MI_LAUNCH_CHECK("wgradC_kernel");
+        if (pb.splits > 1) return mi_launch_split_reduce(st, outp, dw, (long)wsz9, pb.splits, wsz9);
+        return 0;
+    }
     WgPlan p;
     if (wgrad_plan(N, C, H, K, k, stride, &p) || H % stride) { mi_record_error("mid_conv_wgrad", "unsupported shape"); return -2; }
     const size_t wsz = (size_t)K * C * k * k;
@@ -488,8 +719,8 @@ int mid_conv_wgrad(mid_stream s, mid_workspace *ws, const float *x, const float 
     int rc = -2;
     if (k == 3 && stride == 1 && p.tkl == 2) rc = launch_wgrad_t<3, 1, 2, 2, 9>(st, x, dy, part, a, grid);
     else if (k == 3 && stride == 1 && p.tkl == 1) rc = launch_wgrad_t<3, 1, 1, 2, 9>(st, x, dy, part, a, grid);
-    else if (k == 3 && stride == 2 && p.tkl == 2) rc = launch_wgrad_t<3, 2, 2, 1, 15>(st, x, dy, part, a, grid);
-    else if (k == 3 && stride == 2 && p.tkl == 1) rc = launch_wgrad_t<3, 2, 1, 1, 15>(st, x, dy, part, a, grid);
+    else if (k == 3 && stride == 2 && p.tkl == 2) rc = launch_wgrad_t<3, 2, 2, 2, 9>(st, x, dy, part, a, grid);
+    else if (k == 3 && stride == 2 && p.tkl == 1) rc = launch_wgrad_t<3, 2, 1, 2, 9>(st, x, dy, part, a, grid);
     else if (k == 7 && stride == 2) rc = launch_wgrad_t<7, 2, 1, 1, 7>(st, x, dy, part, a, grid);
     if (rc) return rc;
     if (p.splits > 1) return mi_launch_split_reduce(st, part, dw, (long)wsz, p.splits, wsz);
