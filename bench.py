@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="disable the per-kernel HIP-event timing")
     ap.add_argument("--bucket-mb", type=int, default=32)
+    ap.add_argument("--force-dist", action="store_true", help="run the torch.distributed + RCCL path even with one rank (self-test)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -81,7 +82,9 @@ def main():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback exists)")
 
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29571")
         import torch.distributed as dist  # rendezvous + barrier + max-reduce only (gloo); collectives are RCCL in C
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
@@ -90,7 +93,7 @@ def main():
     # every rank draws its own slice of the global batch: distinct image/label streams per rank
     from resnet_amd import dp
     tr.source_synthetic(*dp.rank_seeds(rank), pool_batches=2)
-    if world > 1:
+    if dist is not None:
         dp.init_data_parallel(tr, dist, rank, world, args.bucket_mb)
 
     def barrier():

@@ -299,6 +299,8 @@ int mi_op_adam(float *p, const float *g, float *m, float *v, size_t n, float lr,
                float cur_b1, float cur_b2, float eps, int *nan_flag_dev);
 int mi_op_nhwc_to_nchw(const float *in, float *out, int N, int H, int W, int C);
 /* device-side seeded fill (splitmix64 counter stream, uniform [lo,hi)) -- synthetic operands for micro-benchmarks */
+/* test aid: leaves NaNs in the LDS of every CU (catches kernels that read LDS they did not write) */
+int mi_debug_poison_lds(void);
 int mi_op_fill_uniform(float *out, size_t n, uint64_t seed, float lo, float hi);
 
 #ifdef __cplusplus

@@ -163,6 +163,7 @@ PROTOTYPES = {
     "mi_op_adam": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _f, _vp]),
     "mi_op_nhwc_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i]),
     "mi_op_fill_uniform": (_i, [_vp, _sz, _u64, _f, _f]),
+    "mi_debug_poison_lds": (_i, []),
 }
 
 _lib = None

@@ -15,6 +15,7 @@
 //    segment is held one element per lane in a VGPR and broadcast with v_readlane (SGPR operand again);
 //    dY tiles go through LDS ([k][pixel], odd pitch, conflict-free).  The N*Ho*Wo reduction is split
 //    across workgroups; partial sums are reduced by a second, order-fixed kernel (deterministic).
+#include <stdlib.h>
 #include "mi_common.hpp"
 #include "mi_device.h"
 
@@ -175,9 +176,9 @@ static int launch_dconv_t(hipStream_t st, dim3 grid, size_t lds, int tk, int jm,
                           const float *addend, const DConvArgs &a) {
     dim3 block(448);
 #define DCL(TK_, JM_, CCM_) hipLaunchKernelGGL((dconv_kernel<NTR, NTC, TK_, JM_, CCM_>), grid, block, lds, st, in, wT, out, addend, a)
-    if (jm <= 2) { if (tk == 32) DCL(32, 2, 8); else DCL(16, 2, 8); }
-    else if (jm <= 5) { if (tk == 32) DCL(32, 5, 3); else DCL(16, 5, 3); }
-    else { if (tk == 32) DCL(32, 7, 3); else DCL(16, 7, 3); }
+    if (jm <= 2) { if (tk == 64) DCL(64, 2, 8); else if (tk == 32) DCL(32, 2, 8); else DCL(16, 2, 8); }
+    else if (jm <= 5) { if (tk == 64) DCL(64, 5, 3); else if (tk == 32) DCL(32, 5, 3); else DCL(16, 5, 3); }
+    else { if (tk == 64) DCL(64, 7, 3); else if (tk == 32) DCL(32, 7, 3); else DCL(16, 7, 3); }
 #undef DCL
     return 0;
 }
@@ -210,7 +211,10 @@ static int launch_dconv(hipStream_t st, const float *in, const float *wT, float 
     if (lds > 64 * 1024) { mi_record_error("dconv", "LDS patch too large for this shape"); return -2; }
     a.fd_Wsub = make_fastdiv(a.Wsub); a.fd_Hsub = make_fastdiv(a.Hsub);
     a.fd_Hq = make_fastdiv(a.Hq); a.fd_PW = make_fastdiv(a.PW);
-    const int tk = (a.Cout % 32 == 0) ? 32 : 16;
+    static int tk_pref = -1; /* experiment knob: RESNET_MI_DCONV_TK=64|32 */
+    if (tk_pref < 0) { const char *e = getenv("RESNET_MI_DCONV_TK"); tk_pref = e ? atoi(e) : 32; }
+    int tk = (a.Cout % 32 == 0) ? 32 : 16;
+    if (tk_pref == 64 && a.Cout % 64 == 0) tk = 64;
     if (a.Cout % 16 != 0) { mi_record_error("dconv", "channel count must be a multiple of 16"); return -2; }
     dim3 grid(mi_cdiv(a.total_pix, PIX), a.Cout / tk);
     // algorithmic work of this launch: 2*taps MACs per (pixel, cin, cout); bytes = input + weights + output once
@@ -414,7 +418,9 @@ wgradC_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *
     for (int t = 0; t < 9; t++)
 #pragma unroll
         for (int kp = 0; kp < 4; kp++) acc[t][kp] = (f32x2){0.f, 0.f};
-    for (int i = tid; i < 16; i += 256) xsm[64 * a.pitch + i] = 0.f; // slack read by masked tail columns
+    // masked tail columns of a row read past the patch row (next row / pitch pad / slack) and multiply it by dY = 0:
+    // everything they can touch must be finite, so the whole x region starts zeroed (pads are never rewritten)
+    for (int i = tid; i < a.xs_floats; i += 256) xsm[i] = 0.f;
     float pre[JM], pred[4];
     // dY tile slot of this thread: the same (row, column) for its 4 k-rows
     const int ps = tid & 31;

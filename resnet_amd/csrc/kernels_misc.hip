@@ -185,7 +185,20 @@ __global__ void fill_labels_kernel(int *__restrict__ out, size_t n, uint64_t see
         out[i] = (int)(splitmix64_at(seed, offset + i) % (uint64_t)n_classes);
 }
 
+// ---- test aid: leave NaNs in every CU's LDS so kernels that read LDS they never wrote are caught ----
+__global__ void __launch_bounds__(1024) lds_poison_kernel(float *sink) {
+    extern __shared__ float p[];
+    for (int i = threadIdx.x; i < 16000; i += blockDim.x) p[i] = __int_as_float(0x7fc00000);
+    __syncthreads();
+    if (sink && threadIdx.x == 0 && p[blockIdx.x & 1023] == 0.f) sink[0] = 1.f;
+}
+
 extern "C" {
+int mid_lds_poison(mid_stream s) {
+    hipLaunchKernelGGL(lds_poison_kernel, dim3(2048), dim3(1024), 64000, (hipStream_t)s, (float *)nullptr);
+    MI_LAUNCH_CHECK("lds_poison_kernel");
+    return 0;
+}
 int mid_maxpool_fwd(mid_stream s, const float *x, float *y, int *max_inds, int N, int C, int H, int k, int stride) {
     const int Ho = H / stride;
     const size_t total = (size_t)N * C * Ho * Ho;

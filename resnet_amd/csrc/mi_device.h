@@ -106,6 +106,7 @@ int mid_nhwc_to_nchw(mid_stream s, const float *in, float *out, int N, int H, in
 int mid_nchw_to_nhwc(mid_stream s, const float *in, float *out, int N, int C, int H, int W);
 /* splitmix64 counter streams on device (synthetic batches): uniform in [lo,hi) / labels mod n_classes */
 int mid_fill_uniform(mid_stream s, float *out, size_t n, uint64_t seed, uint64_t offset, float lo, float hi);
+int mid_lds_poison(mid_stream s); /* test aid: fills LDS of every CU with NaNs */
 int mid_fill_labels(mid_stream s, int *out, size_t n, uint64_t seed, uint64_t offset, int n_classes);
 
 /* ---- RCCL (resolved with dlopen at first use) ---- */

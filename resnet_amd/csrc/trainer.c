@@ -559,7 +559,7 @@ void backwards_pass(Train_ResNet *t) {
  * (the order update_parameters walks, resnet.cu:2952). */
 void mi_dp_reduce_ready(Train_ResNet *t, size_t from, int force) {
     MiCtx *c = ctx_of(t);
-    if (c->world <= 1 || !c->comm) return;
+    if (!c->comm) return;
     if (from >= c->dp_cursor) return;
     const size_t n = c->dp_cursor - from;
     if (!force && n * sizeof(float) < c->bucket_bytes) return;
@@ -649,7 +649,9 @@ int mi_dp_unique_id_bytes(void) { return mid_rccl_unique_id_bytes(); }
 int mi_dp_get_unique_id(void *out, int bytes) { return mid_rccl_get_unique_id(out, bytes); }
 int mi_dp_init(Train_ResNet *t, int rank, int world, const void *unique_id, int bytes) {
     MiCtx *c = ctx_of(t);
-    if (world <= 1) { c->world = 1; return 0; }
+    if (world < 1 || rank < 0 || rank >= world) return -1;
+    if (world == 1 && !unique_id) { c->world = 1; return 0; }
+    /* world == 1 with an id builds a one-rank communicator: the whole bucket/stream/event path runs (self-test) */
     c->comm = mid_rccl_comm_init(rank, world, unique_id, bytes);
     if (!c->comm) return -1;
     c->rank = rank; c->world = world;

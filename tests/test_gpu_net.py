@@ -152,3 +152,27 @@ def test_weight_init_matches_stream():
         got = tr.get("params", i)
         assert np.allclose(got, r, rtol=1e-6, atol=1e-9), "location %d" % i
     tr.close()
+
+
+def test_data_parallel_path_single_rank(oracle):
+    """the RCCL bucket / second-stream / event path with a one-rank communicator: all-reduce(SUM) over one rank
+    is the identity, so the step must still match the oracle -- exercises dlopen(librccl), ncclCommInitRank,
+    bucketed ncclAllReduce on the comm stream and the Adam wait on this box's single GPU"""
+    import ctypes as C
+    dims, batch = synth.C1S_DIMS, 4
+    net, tr = _make(dims, batch, oracle)
+    try:
+        nbytes = tr.L.mi_dp_unique_id_bytes()
+        uid = (C.c_char * nbytes)()
+        assert tr.L.mi_dp_get_unique_id(uid, nbytes) == 0, tr.error()
+        assert tr.L.mi_dp_init(tr.t, 0, 1, uid, nbytes) == 0, tr.error()
+        tr.L.mi_dp_set_bucket_bytes(tr.t, 64 << 10)  # small buckets: several all-reduces per backward
+        for step in range(2):
+            _step(net, tr, dims, batch, step)
+            net.backward(); tr.backward(); tr.check()
+            net.update(); tr.update(); tr.check()
+            for i in range(net.n_locations):
+                assert rel_l2(tr.get("params", i), net.param(i)) <= PARAM_REL_L2, "param %d step %d" % (i, step)
+    finally:
+        tr.close()
+        net.close()

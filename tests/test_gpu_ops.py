@@ -73,6 +73,21 @@ def test_conv_wgrad(ops, oracle, shape):
     check_grad(got, ref, "conv_wgrad %s" % (shape,))
 
 
+@pytest.mark.parametrize("shape", [(256, 14, 256, 3, 1, 3), (512, 7, 512, 3, 1, 5), (512, 14, 512, 3, 2, 2), (64, 8, 64, 3, 1, 4)])
+def test_conv_kernels_do_not_read_unwritten_lds(ops, oracle, shape):
+    """rows padded to whole pixel quads multiply stale LDS by dY = 0: with NaNs left in LDS by another kernel
+    that must still be finite (regression: full-size step produced NaN gradients)"""
+    C, H, K, k, stride, N = shape
+    x, w, dy = _conv_data(*shape)
+    for fn, ref in ((lambda: ops.conv_wgrad(nchw(x), nchw(dy), k, stride), oracle.conv_wgrad(x, dy, k, stride)),
+                    (lambda: nhwc(ops.conv_fwd(nchw(x), w, stride)), oracle.conv_fwd(x, w, stride)),
+                    (lambda: nhwc(ops.conv_dgrad(w, nchw(dy), H, stride)), oracle.conv_dgrad(w, dy, H, stride))):
+        assert ops.L.mi_debug_poison_lds() == 0
+        got = fn()
+        assert np.all(np.isfinite(got))
+        check_grad(got, ref, "after LDS poison %s" % (shape,))
+
+
 BN_SHAPES = [(64, 112, 2), (64, 56, 3), (256, 56, 2), (512, 28, 3), (1024, 14, 4), (2048, 7, 6), (512, 7, 5), (64, 8, 4), (256, 8, 4)]
 
 
