@@ -215,6 +215,7 @@ static int launch_dconv(hipStream_t st, const float *in, const float *wT, float 
     if (tk_pref < 0) { const char *e = getenv("RESNET_MI_DCONV_TK"); tk_pref = e ? atoi(e) : 32; }
     int tk = (a.Cout % 32 == 0) ? 32 : 16;
     if (tk_pref == 64 && a.Cout % 64 == 0) tk = 64;
+    if (tk_pref == 16) tk = 16;
     if (a.Cout % 16 != 0) { mi_record_error("dconv", "channel count must be a multiple of 16"); return -2; }
     dim3 grid(mi_cdiv(a.total_pix, PIX), a.Cout / tk);
     // algorithmic work of this launch: 2*taps MACs per (pixel, cin, cout); bytes = input + weights + output once
@@ -392,7 +393,7 @@ struct WcArgs {
     int N, C, H, W, K, Ho, Wo, pad;
     int NPX, rows, segw, QPR, DP, cpp, chunks_total, chunks_per_split;
     int PR, PW, cwlog2, pitch, jcnt, xs_floats;
-    FastDiv fd_cpp, fd_Wo, fd_PR, fd_Q4;
+    FastDiv fd_cpp, fd_Wo, fd_PR, fd_Q4, fd_PW;
     size_t part_stride;
 };
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -402,15 +403,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int S>
 __global__ void __launch_bounds__(256)
 wgradC_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ part, const WcArgs a) {
-    constexpr int JM = 24, NXW = 3 * S + 3;
+    constexpr int NXW = 3 * S + 3;
     extern __shared__ float sm[];
     float *xsm = sm;                 // [64][pitch] + slack
     float *dys = sm + a.xs_floats;   // [32][DP]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kb0 = blockIdx.x * 32, cb = blockIdx.y * 64;
-    const int rpi = 64 >> a.cwlog2, col = lane & ((1 << a.cwlog2) - 1), sub = lane >> a.cwlog2;
-    const int npairs = 64 * a.PR, plane_o = a.Ho * a.Wo;
+    const int plane_o = a.Ho * a.Wo;
     // accumulators as k-pairs: v_pk_fma_f32 takes (dY[k], dY[k+1]) straight out of a ds_read_b128 and the x value
     // as a broadcast half -- no register shuffling to feed the packed FMA
     f32x2 acc[9][4];
@@ -421,30 +421,47 @@ wgradC_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *
     // masked tail columns of a row read past the patch row (next row / pitch pad / slack) and multiply it by dY = 0:
     // everything they can touch must be finite, so the whole x region starts zeroed (pads are never rewritten)
     for (int i = tid; i < a.xs_floats; i += 256) xsm[i] = 0.f;
-    float pre[JM], pred[4];
+    // x staging: wave w stages channels w*16 .. w*16+15; lane l owns patch positions l and l+64 (row, col fixed for
+    // the whole kernel), so a slot costs one scalar channel base + one per-lane constant offset
+    float pre[2][16], pred[4];
+    const int patch = a.PR * a.PW;
+    int prow[2], pcol[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int pos = lane + 64 * h;
+        const uint32_t r = fd_div((uint32_t)pos, a.fd_PW);
+        prow[h] = (int)r; pcol[h] = pos - (int)r * a.PW;
+    }
     // dY tile slot of this thread: the same (row, column) for its 4 k-rows
     const int ps = tid & 31;
     const uint32_t dr = fd_div((uint32_t)ps, a.fd_Q4);
     const int dq = ps - (int)dr * (a.QPR * 4);
     const bool dslot = ps < a.rows * a.QPR * 4;
 
-    auto issue = [&](int ch, int z) {
+    auto issue = [&](int ch) {
         const uint32_t n = fd_div((uint32_t)ch, a.fd_cpp);
         const int p0 = (ch - (int)n * a.cpp) * a.NPX;
         const int npx = min(a.NPX, plane_o - p0);
         const uint32_t oh0 = fd_div((uint32_t)p0, a.fd_Wo);
-        const int ih0 = (int)oh0 * S - a.pad, iw = (p0 - (int)oh0 * a.Wo) * S - a.pad + col;
-        const bool colok = col < a.PW && iw >= 0 && iw < a.W;
+        const int ih0 = (int)oh0 * S - a.pad, iw0 = (p0 - (int)oh0 * a.Wo) * S - a.pad;
+        int off[2];
+        bool ok[2];
 #pragma unroll
-        for (int j = 0; j < JM; j++) {
-            const int pi = (wave + 4 * j) * rpi + sub + z; // z: opaque 0, keeps this arithmetic out of registers
-            float v = 0.f;
-            if (j < a.jcnt && pi < npairs && colok) {
-                const uint32_t c = fd_div((uint32_t)pi, a.fd_PR);
-                const int ih = ih0 + pi - (int)c * a.PR;
-                if (ih >= 0 && ih < a.H) v = x[(((size_t)n * a.C + cb + c) * a.H + ih) * a.W + iw];
+        for (int h = 0; h < 2; h++) {
+            const int ih = ih0 + prow[h], iw = iw0 + pcol[h];
+            ok[h] = lane + 64 * h < patch && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+            off[h] = ih * a.W + iw;
+        }
+        const float *xb = x + ((size_t)n * a.C + cb + wave * 16) * a.H * a.W; // wave-uniform
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const float *xc = xb + (size_t)j * a.H * a.W;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                float v = 0.f;
+                if (ok[h]) v = xc[off[h]];
+                pre[h][j] = v;
             }
-            pre[j] = v;
         }
         const int pix = (int)dr * a.segw + dq;
         const bool dok = dslot && dq < a.segw && pix < npx;
@@ -456,13 +473,13 @@ wgradC_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *
             pred[j] = v;
         }
     };
-    auto stash = [&](int z) {
+    auto stash = [&]() {
+        float *xw_ = xsm + wave * 16 * a.pitch + lane;
 #pragma unroll
-        for (int j = 0; j < JM; j++) {
-            const int pi = (wave + 4 * j) * rpi + sub + z;
-            if (j < a.jcnt && pi < npairs && col < a.PW) {
-                const uint32_t c = fd_div((uint32_t)pi, a.fd_PR);
-                xsm[c * a.pitch + (pi - (int)c * a.PR) * a.PW + col] = pre[j];
+        for (int h = 0; h < 2; h++) {
+            if (lane + 64 * h < patch) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) xw_[j * a.pitch + 64 * h] = pre[h][j];
             }
         }
         if (dslot) {
@@ -473,16 +490,14 @@ wgradC_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *
 
     const int ch_beg = blockIdx.z * a.chunks_per_split;
     const int ch_end = min(a.chunks_total, ch_beg + a.chunks_per_split);
-    int z = 0;
-    if (ch_beg < ch_end) issue(ch_beg, 0);
+    if (ch_beg < ch_end) issue(ch_beg);
     const float *xl = xsm + lane * a.pitch;
     const float *dw = dys + wave * 8;
     for (int ch = ch_beg; ch < ch_end; ch++) {
-        asm volatile("v_mov_b32 %0, 0" : "=v"(z));
         __syncthreads();
-        stash(z);
+        stash();
         __syncthreads();
-        if (ch + 1 < ch_end) issue(ch + 1, z);
+        if (ch + 1 < ch_end) issue(ch + 1);
         for (int r = 0; r < a.rows; r++) {
             for (int q = 0; q < a.QPR; q++) {
                 float xw[3][NXW];
@@ -537,8 +552,8 @@ static int wgradB_plan(int N, int C, int H, int K, int k, int stride, WbPlan *p)
     if (p->PW > 32) return -1;
     p->cwlog2 = p->PW > 16 ? 5 : 4;
     p->pitch = (p->PR * p->PW) | 1;
-    p->jcnt = mi_cdiv(64 * p->PR, 4 * (64 >> p->cwlog2));
-    if (p->jcnt > 24) return -1;
+    p->jcnt = 0;
+    if (p->PR * p->PW > 128) return -1; /* two patch positions per lane */
     p->cpp = mi_cdiv(Wo * Wo, npx);
     p->chunks = N * p->cpp;
     const int base_blocks = (K / 32) * (C / 64);
@@ -696,7 +711,7 @@ int mid_conv_wgrad(mid_stream s, mid_workspace *ws, const float *x, const float 
         b.PR = pb.PR; b.PW = pb.PW; b.cwlog2 = pb.cwlog2; b.pitch = pb.pitch; b.jcnt = pb.jcnt;
         b.xs_floats = (64 * pb.pitch + 16 + 3) & ~3;
         b.fd_cpp = make_fastdiv(pb.cpp); b.fd_Wo = make_fastdiv(b.Wo); b.fd_PR = make_fastdiv(pb.PR);
-        b.fd_Q4 = make_fastdiv(pb.qpr * 4);
+        b.fd_Q4 = make_fastdiv(pb.qpr * 4); b.fd_PW = make_fastdiv(pb.PW);
         b.part_stride = wsz9;
         float *outp = pb.splits == 1 ? dw : ws->part;
         dim3 grid(K / 32, C / 64, pb.splits);

@@ -7,9 +7,9 @@
 //   forward  Y[n][k][p]  = sum_c W[k][c]  X[n][c][p]     M=K_out, N=(n,p) "batched column", K=C
 //   dgrad    dX[n][c][p] = sum_k W[k][c]  dY[n][k][p]    M=C,     N=(n,p),                 K=K_out
 //   wgrad    dW[k][c]    = sum_(n,p) dY[n][k][p] X[n][c][p]   M=K_out, N=C, K=(n,p) "batched K", split over z
-// Tile 128x128x16 (or 64x128x16), 256 threads = 4 waves, each wave a 64x64 (64x32) block of 32x32 MFMA
+// Tile 128x128x32 (or 64x128x32), 256 threads = 4 waves, each wave a 64x64 (64x32) block of 32x32 MFMA
 // tiles; operands staged k-major in LDS (pitch 130: conflict-free for both the staging writes and the
-// lane=row fragment reads), next tile prefetched into registers while the current one is multiplied.
+// lane=row fragment reads), 16-byte global loads where the contiguous dim allows, next tile prefetched into registers while the current one is multiplied.
 #include "mi_common.hpp"
 #include "mi_device.h"
 
@@ -32,48 +32,31 @@ struct GemmArgs {
 
 enum { BATCH_NONE = 0, BATCH_N = 1, BATCH_K = 2 };
 
-#define G_BK 16
-#define G_LD 130
+#define G_BK 32
+#define G_LDK 129 /* pitch of a K-contiguous operand staged transposed (4 scalar stores per float4: conflict-free) */
+#define G_LDN 132 /* pitch of an M/N-contiguous operand staged with ds_write_b128 (16-B aligned rows) */
+
+typedef float gf4 __attribute__((ext_vector_type(4)));
 
 // A_KC: A's contiguous dim is K (else M).  B_KC: B's contiguous dim is K (else N).
-template <int BM, int BATCH, bool A_KC, bool B_KC>
+// VA / VB: the operand may be fetched with 16-byte loads along its contiguous dim (sizes % 4 == 0, 16-B aligned).
+template <int BM, int BATCH, bool A_KC, bool B_KC, bool VA, bool VB>
 __global__ void __launch_bounds__(256)
 gemm_mfma_kernel(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
                  const float *__restrict__ addend, const GemmArgs g) {
     constexpr int BN = 128;
     constexpr int WM = 64, WN = (BM == 128) ? 64 : 32;     // per-wave tile
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int AE = BM * G_BK / 256, BE = BN * G_BK / 256; // elements per thread per tile
-    __shared__ float As[G_BK * G_LD];
-    __shared__ float Bs[G_BK * G_LD];
+    constexpr int LDA = A_KC ? G_LDK : G_LDN, LDB = B_KC ? G_LDK : G_LDN;
+    constexpr int AV = BM * G_BK / 1024, BV = BN * G_BK / 1024;  // float4 per thread per tile
+    constexpr int AE = BM * G_BK / 256, BE = BN * G_BK / 256;    // scalars per thread per tile
+    __shared__ __attribute__((aligned(16))) float As[G_BK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[G_BK * LDB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = (BM == 128) ? (wave >> 1) : 0, wn = (BM == 128) ? (wave & 1) : wave;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int kbeg = blockIdx.z * g.klen, kend = min(g.K, kbeg + g.klen);
-
-    // ---- per-thread staging coordinates ----
-    // K-contiguous operand: kk = tid % 16, row = tid / 16 + 16*q.  M/N-contiguous: row = tid % R, kk = tid / R + (256/R)*q
-    int a_i[AE], a_k[AE];
-    long a_off[AE];
-#pragma unroll
-    for (int q = 0; q < AE; q++) {
-        if (A_KC) { a_k[q] = tid & 15; a_i[q] = (tid >> 4) + 16 * q; }
-        else { a_i[q] = tid % BM; a_k[q] = tid / BM + (256 / BM) * q; }
-        a_off[q] = (long)(m0 + a_i[q]) * g.a_sm;
-    }
-    int b_j[BE], b_k[BE];
-    long b_off[BE];
-#pragma unroll
-    for (int q = 0; q < BE; q++) {
-        if (B_KC) { b_k[q] = tid & 15; b_j[q] = (tid >> 4) + 16 * q; }
-        else { b_j[q] = tid & 127; b_k[q] = (tid >> 7) + 2 * q; }
-        const int j = n0 + b_j[q];
-        if (BATCH == BATCH_N) {
-            const uint32_t n = fd_div((uint32_t)min(j, g.N - 1), g.fdP);
-            b_off[q] = (long)n * g.b_sb + (min(j, g.N - 1) - (long)n * g.P);
-        } else b_off[q] = (long)j * g.b_sn;
-    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -83,38 +66,111 @@ gemm_mfma_kernel(const float *__restrict__ A, const float *__restrict__ B, float
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    float ra[AE], rb[BE];
+    // element offset of (row-ish index, kk) for each operand; `row` is m (A) or n (B)
+    auto a_addr = [&](int i, int kk) -> long {
+        long off = (long)(m0 + i) * g.a_sm;
+        if (BATCH == BATCH_K) { const uint32_t n = fd_div((uint32_t)kk, g.fdP); off += (long)n * g.a_sb + (kk - (long)n * g.P); }
+        else off += (long)kk * g.a_sk;
+        return off;
+    };
+    auto b_addr = [&](int j, int kk) -> long {
+        const int col = n0 + j;
+        long off;
+        if (BATCH == BATCH_N) { const uint32_t n = fd_div((uint32_t)col, g.fdP); off = (long)n * g.b_sb + (col - (long)n * g.P) + (long)kk * g.b_sk; }
+        else if (BATCH == BATCH_K) { const uint32_t n = fd_div((uint32_t)kk, g.fdP); off = (long)col * g.b_sn + (long)n * g.b_sb + (kk - (long)n * g.P); }
+        else off = (long)col * g.b_sn + (long)kk * g.b_sk;
+        return off;
+    };
+
+    gf4 ra4[VA ? AV : 1], rb4[VB ? BV : 1];
+    float ra[VA ? 1 : AE], rb[VB ? 1 : BE];
     auto load_tile = [&](int k0) {
+        if (VA) {
 #pragma unroll
-        for (int q = 0; q < AE; q++) {
-            const int kk = k0 + a_k[q];
-            float v = 0.f;
-            if (m0 + a_i[q] < g.M && kk < kend) {
-                long off = a_off[q];
-                if (BATCH == BATCH_K) { const uint32_t n = fd_div((uint32_t)kk, g.fdP); off += (long)n * g.a_sb + (kk - (long)n * g.P); }
-                else off += (long)kk * g.a_sk;
-                v = A[off];
+            for (int q = 0; q < AV; q++) {
+                int i, kk;
+                if (A_KC) { kk = (tid & 7) * 4; i = (tid >> 3) + 32 * q; }
+                else { i = (tid & (BM / 4 - 1)) * 4; kk = tid / (BM / 4) + (1024 / BM) * q; }
+                gf4 v = {0.f, 0.f, 0.f, 0.f};
+                if (m0 + i < g.M && k0 + kk < kend) v = *(const gf4 *)(A + a_addr(i, k0 + kk));
+                ra4[q] = v;
             }
-            ra[q] = v;
+        } else {
+#pragma unroll
+            for (int q = 0; q < AE; q++) {
+                int i, kk;
+                if (A_KC) { kk = tid & 31; i = (tid >> 5) + 8 * q; }
+                else { i = tid % BM; kk = tid / BM + (256 / BM) * q; }
+                float v = 0.f;
+                if (m0 + i < g.M && k0 + kk < kend) v = A[a_addr(i, k0 + kk)];
+                ra[q] = v;
+            }
         }
+        if (VB) {
 #pragma unroll
-        for (int q = 0; q < BE; q++) {
-            const int kk = k0 + b_k[q];
-            float v = 0.f;
-            if (n0 + b_j[q] < g.N && kk < kend) {
-                long off = b_off[q];
-                if (BATCH == BATCH_K) { const uint32_t n = fd_div((uint32_t)kk, g.fdP); off += (long)n * g.b_sb + (kk - (long)n * g.P); }
-                else off += (long)kk * g.b_sk;
-                v = B[off];
+            for (int q = 0; q < BV; q++) {
+                int j, kk;
+                if (B_KC) { kk = (tid & 7) * 4; j = (tid >> 3) + 32 * q; }
+                else { j = (tid & 31) * 4; kk = (tid >> 5) + 8 * q; }
+                gf4 v = {0.f, 0.f, 0.f, 0.f};
+                if (n0 + j < g.N && k0 + kk < kend) v = *(const gf4 *)(B + b_addr(j, k0 + kk));
+                rb4[q] = v;
             }
-            rb[q] = v;
+        } else {
+#pragma unroll
+            for (int q = 0; q < BE; q++) {
+                int j, kk;
+                if (B_KC) { kk = tid & 31; j = (tid >> 5) + 8 * q; }
+                else { j = tid & 127; kk = (tid >> 7) + 2 * q; }
+                float v = 0.f;
+                if (n0 + j < g.N && k0 + kk < kend) v = B[b_addr(j, k0 + kk)];
+                rb[q] = v;
+            }
         }
     };
     auto store_tile = [&]() {
+        if (VA) {
 #pragma unroll
-        for (int q = 0; q < AE; q++) As[a_k[q] * G_LD + a_i[q]] = ra[q];
+            for (int q = 0; q < AV; q++) {
+                if (A_KC) {
+                    const int kk = (tid & 7) * 4, i = (tid >> 3) + 32 * q;
 #pragma unroll
-        for (int q = 0; q < BE; q++) Bs[b_k[q] * G_LD + b_j[q]] = rb[q];
+                    for (int e = 0; e < 4; e++) As[(kk + e) * LDA + i] = ra4[q][e];
+                } else {
+                    const int i = (tid & (BM / 4 - 1)) * 4, kk = tid / (BM / 4) + (1024 / BM) * q;
+                    *(gf4 *)(As + kk * LDA + i) = ra4[q];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < AE; q++) {
+                int i, kk;
+                if (A_KC) { kk = tid & 31; i = (tid >> 5) + 8 * q; }
+                else { i = tid % BM; kk = tid / BM + (256 / BM) * q; }
+                As[kk * LDA + i] = ra[q];
+            }
+        }
+        if (VB) {
+#pragma unroll
+            for (int q = 0; q < BV; q++) {
+                if (B_KC) {
+                    const int kk = (tid & 7) * 4, j = (tid >> 3) + 32 * q;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) Bs[(kk + e) * LDB + j] = rb4[q][e];
+                } else {
+                    const int j = (tid & 31) * 4, kk = (tid >> 5) + 8 * q;
+                    *(gf4 *)(Bs + kk * LDB + j) = rb4[q];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < BE; q++) {
+                int j, kk;
+                if (B_KC) { kk = tid & 31; j = (tid >> 5) + 8 * q; }
+                else { j = tid & 127; kk = (tid >> 7) + 2 * q; }
+                Bs[kk * LDB + j] = rb[q];
+            }
+        }
     };
 
     load_tile(kbeg);
@@ -128,9 +184,9 @@ gemm_mfma_kernel(const float *__restrict__ A, const float *__restrict__ B, float
         for (int k2 = 0; k2 < G_BK; k2 += 2) {
             float av[TM], bv[TN];
 #pragma unroll
-            for (int i = 0; i < TM; i++) av[i] = As[(k2 + fk) * G_LD + wm * WM + i * 32 + fr];
+            for (int i = 0; i < TM; i++) av[i] = As[(k2 + fk) * LDA + wm * WM + i * 32 + fr];
 #pragma unroll
-            for (int j = 0; j < TN; j++) bv[j] = Bs[(k2 + fk) * G_LD + wn * WN + j * 32 + fr];
+            for (int j = 0; j < TN; j++) bv[j] = Bs[(k2 + fk) * LDB + wn * WN + j * 32 + fr];
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -166,7 +222,7 @@ gemm_mfma_kernel(const float *__restrict__ A, const float *__restrict__ B, float
 
 template <int BATCH, bool A_KC, bool B_KC>
 static int launch_gemm(hipStream_t st, const float *A, const float *B, float *C, const float *addend, GemmArgs g,
-                       int splits) {
+                       int splits, bool va, bool vb) {
     g.fdP = make_fastdiv(g.P > 0 ? g.P : 1);
     if (splits < 1) splits = 1;
     int klen = mi_cdiv(g.K, splits);
@@ -177,8 +233,11 @@ static int launch_gemm(hipStream_t st, const float *A, const float *B, float *C,
     dim3 grid(mi_cdiv(g.N, 128), mi_cdiv(g.M, bm), splits), block(256);
     mi_prof_begin(st, MI_FAM_GEMM, 2.0 * (double)g.M * g.N * g.K,
                   4.0 * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N * (addend ? 2 : 1)));
-    if (bm == 64) hipLaunchKernelGGL((gemm_mfma_kernel<64, BATCH, A_KC, B_KC>), grid, block, 0, st, A, B, C, addend, g);
-    else hipLaunchKernelGGL((gemm_mfma_kernel<128, BATCH, A_KC, B_KC>), grid, block, 0, st, A, B, C, addend, g);
+    if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) va = vb = false;
+#define GL(BM_, VA_, VB_) hipLaunchKernelGGL((gemm_mfma_kernel<BM_, BATCH, A_KC, B_KC, VA_, VB_>), grid, block, 0, st, A, B, C, addend, g)
+    if (bm == 64) { if (va && vb) GL(64, true, true); else if (va) GL(64, true, false); else GL(64, false, false); }
+    else { if (va && vb) GL(128, true, true); else if (va) GL(128, true, false); else GL(128, false, false); }
+#undef GL
     mi_prof_end(st);
     MI_LAUNCH_CHECK("gemm_mfma_kernel");
     return splits;
@@ -193,7 +252,7 @@ int mi_conv1x1_fwd(hipStream_t st, const float *x, const float *w, float *y, int
     g.a_sm = C; g.a_sk = 1;
     g.b_sk = P; g.b_sb = (long)C * P;
     g.c_sm = P; g.c_sb = (long)K * P;
-    return launch_gemm<BATCH_N, true, false>(st, w, x, y, nullptr, g, 1) > 0 ? 0 : -1;
+    return launch_gemm<BATCH_N, true, false>(st, w, x, y, nullptr, g, 1, C % 4 == 0, P % 4 == 0) > 0 ? 0 : -1;
 }
 // dX[n][c][p] = sum_k W[k][c] dY[n][k][p] (+ addend)
 int mi_conv1x1_dgrad(hipStream_t st, const float *w, const float *dy, float *dx, const float *addend, int N, int C,
@@ -203,7 +262,7 @@ int mi_conv1x1_dgrad(hipStream_t st, const float *w, const float *dy, float *dx,
     g.a_sm = 1; g.a_sk = C;
     g.b_sk = P; g.b_sb = (long)K * P;
     g.c_sm = P; g.c_sb = (long)C * P;
-    return launch_gemm<BATCH_N, false, false>(st, w, dy, dx, addend, g, 1) > 0 ? 0 : -1;
+    return launch_gemm<BATCH_N, false, false>(st, w, dy, dx, addend, g, 1, C % 4 == 0, P % 4 == 0) > 0 ? 0 : -1;
 }
 static int wgrad1x1_splits(int N, int C, int P, int K) {
     const int tiles = mi_cdiv(C, 128) * mi_cdiv(K, K <= 64 ? 64 : 128);
@@ -232,7 +291,7 @@ int mi_conv1x1_wgrad(hipStream_t st, mid_workspace *ws, const float *x, const fl
         return -3;
     }
     float *out = splits > 1 ? ws->part : dw;
-    const int used = launch_gemm<BATCH_K, true, true>(st, dy, x, out, nullptr, g, splits);
+    const int used = launch_gemm<BATCH_K, true, true>(st, dy, x, out, nullptr, g, splits, P % 4 == 0, P % 4 == 0);
     if (used < 0) return -1;
     if (splits > 1) return mi_launch_split_reduce(st, out, dw, (long)K * C, used, (size_t)K * C);
     return 0;
@@ -243,18 +302,18 @@ int mid_gemm_nn(mid_stream s, const float *A, const float *B, float *out, int m,
     GemmArgs g = {};
     g.M = m; g.N = n; g.K = k; g.P = 1;
     g.a_sm = k; g.a_sk = 1; g.b_sk = n; g.b_sn = 1; g.c_sm = n; g.c_sn = 1;
-    return launch_gemm<BATCH_NONE, true, false>((hipStream_t)s, A, B, out, nullptr, g, 1) > 0 ? 0 : -1;
+    return launch_gemm<BATCH_NONE, true, false>((hipStream_t)s, A, B, out, nullptr, g, 1, k % 4 == 0, n % 4 == 0) > 0 ? 0 : -1;
 }
 int mid_gemm_tn(mid_stream s, const float *At, const float *B, float *out, int m, int k, int n) {
     GemmArgs g = {};
     g.M = m; g.N = n; g.K = k; g.P = 1;
     g.a_sm = 1; g.a_sk = m; g.b_sk = n; g.b_sn = 1; g.c_sm = n; g.c_sn = 1;
-    return launch_gemm<BATCH_NONE, false, false>((hipStream_t)s, At, B, out, nullptr, g, 1) > 0 ? 0 : -1;
+    return launch_gemm<BATCH_NONE, false, false>((hipStream_t)s, At, B, out, nullptr, g, 1, m % 4 == 0, n % 4 == 0) > 0 ? 0 : -1;
 }
 int mid_gemm_nt(mid_stream s, const float *A, const float *Bt, float *out, int m, int k, int n) {
     GemmArgs g = {};
     g.M = m; g.N = n; g.K = k; g.P = 1;
     g.a_sm = k; g.a_sk = 1; g.b_sk = 1; g.b_sn = k; g.c_sm = n; g.c_sn = 1;
-    return launch_gemm<BATCH_NONE, true, true>((hipStream_t)s, A, Bt, out, nullptr, g, 1) > 0 ? 0 : -1;
+    return launch_gemm<BATCH_NONE, true, true>((hipStream_t)s, A, Bt, out, nullptr, g, 1, k % 4 == 0, k % 4 == 0) > 0 ? 0 : -1;
 }
 }
