@@ -202,7 +202,9 @@ static int launch_dconv(hipStream_t st, const float *in, const float *wT, float 
     a.jcnt = (a.plane + PIX - 1) / PIX;
     if (a.jcnt > 7) { mi_record_error("dconv", "input patch too large for this shape"); return -2; }
     const int ccm = a.jcnt <= 2 ? 8 : 3;
-    int cc = 5120 / a.plane; // two LDS buffers of <= 20 KB each
+    static int lds_budget = -1; /* floats per LDS buffer; RESNET_MI_DCONV_LDS overrides */
+    if (lds_budget < 0) { const char *e = getenv("RESNET_MI_DCONV_LDS"); lds_budget = e ? atoi(e) : 5120; }
+    int cc = lds_budget / a.plane; // two LDS buffers
     if (cc < 1) cc = 1;
     if (cc > ccm) cc = ccm;
     if (cc > a.Cin) cc = a.Cin;
@@ -565,18 +567,36 @@ static int wgradB_plan(int N, int C, int H, int K, int k, int stride, WbPlan *p)
     return 0;
 }
 
-__global__ void split_reduce_kernel(const float *__restrict__ part, float *__restrict__ out, long n, int splits,
-                                    size_t stride) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+// out[i] = sum_z part[z][i] in a FIXED order (deterministic): a workgroup owns 64 consecutive elements (coalesced
+// 256-B rows), its 4 waves take z = w, w+4, ... with 8 loads in flight each, LDS adds the four partial sums.
+__global__ void __launch_bounds__(256)
+split_reduce_kernel(const float *__restrict__ part, float *__restrict__ out, long n, int splits, size_t stride) {
+    __shared__ float sh[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long base = (long)blockIdx.x * 64; base < n; base += (long)gridDim.x * 64) {
+        const long i = base + lane;
         float s = 0.f;
-        for (int z = 0; z < splits; z++) s += part[(size_t)z * stride + i];
-        out[i] = s;
+        if (i < n) {
+            int z = wave;
+            for (; z + 28 < splits; z += 32) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = part[(size_t)(z + 4 * u) * stride + i];
+#pragma unroll
+                for (int u = 0; u < 8; u++) s += v[u];
+            }
+            for (; z < splits; z += 4) s += part[(size_t)z * stride + i];
+        }
+        sh[wave][lane] = s;
+        __syncthreads();
+        if (wave == 0 && i < n) out[i] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+        __syncthreads();
     }
 }
 
 int mi_launch_split_reduce(hipStream_t st, const float *part, float *out, long n, int splits, size_t stride) {
-    int blocks = mi_cdiv(n, 256);
-    if (blocks > 8192) blocks = 8192;
+    int blocks = mi_cdiv(n, 64);
+    if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(split_reduce_kernel, dim3(blocks), dim3(256), 0, st, part, out, n, splits, stride);
     MI_LAUNCH_CHECK("split_reduce_kernel");
     return 0;
