@@ -101,13 +101,32 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    def read_prof():
+        st = {}
+        for fam in FAMILIES:
+            n, ms, fl, by = C.c_long(0), C.c_double(0), C.c_double(0), C.c_double(0)
+            lib.mi_prof_get(fam, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by))
+            st[fam] = (n.value, ms.value, fl.value, by.value)
+        return st
+
     losses = []
-    for _ in range(args.warmup):
+    prof = not args.no_prof
+    warm_stats, warm_steps = {}, 0
+    for w in range(args.warmup):
+        # the last warm-up step is timed per kernel family (HIP events around every launch cost ~3% of a step, so in
+        # the timed region only the dominant family found here is bracketed)
+        if prof and w == args.warmup - 1:
+            lib.mi_prof_enable(1)
+            lib.mi_prof_reset()
+            warm_steps = 1
         losses.append(tr.step()[0])
     tr.check()
-    prof = not args.no_prof
+    dom = 0
     if prof:
-        lib.mi_prof_enable(1)
+        if warm_steps:
+            warm_stats = read_prof()
+            dom = max(warm_stats, key=lambda f: warm_stats[f][1])
+        lib.mi_prof_enable(1 << dom if dom else 2 | 1)  # family 0 -> mask 1 (value 1 means "all", so add family 1)
         lib.mi_prof_reset()
     barrier()
     t0 = time.perf_counter()
@@ -125,10 +144,7 @@ def main():
 
     fam_stats = {}
     if prof:
-        for fam in FAMILIES:
-            n, ms, fl, by = C.c_long(0), C.c_double(0), C.c_double(0), C.c_double(0)
-            lib.mi_prof_get(fam, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by))
-            fam_stats[fam] = (n.value, ms.value, fl.value, by.value)
+        fam_stats = read_prof()
         lib.mi_prof_enable(0)
     timings = tr.timings()
     tr.close()
@@ -146,7 +162,6 @@ def main():
                                                  "update": round(timings[3], 3)},
                           "final_loss_per_image": round(losses[-1] / args.batch, 4)}}
         if fam_stats:
-            dom = max(fam_stats, key=lambda f: fam_stats[f][1])
             n, ms, fl, by = fam_stats[dom]
             if dom == 3:
                 ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -156,14 +171,28 @@ def main():
                 ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
                 roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": None}
+            # HBM traffic of that family from the committed rocprofv3 PMC passes (bench.py cannot run the profiler itself)
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+                key = {0: "dconv", 1: "wgradC", 2: "gemm", 3: "bn"}[dom]
+                # the PMC passes count kernel launches, this run counts logical launches (the four concurrent stride-2 dgrad
+                # class kernels are one): convert through bytes per step
+                roof["traffic"] = round(pmc["families"][key]["hbm_GB_per_step_raw"] * 1e9 / (n / args.steps))
+                roof["traffic_note"] = ("HBM bytes per launch (FETCH_SIZE+WRITE_SIZE, separate --pmc passes, profiles/r1_pmc_traffic.json; "
+                                        "4-B/lane loads: gfx950 FETCH halving uncalibrated, raw value); algorithmic bytes per launch: %d" % round(by / max(n, 1)))
+            except Exception:
+                pass
             roof["kernel"] = FAMILIES[dom]
             roof["launches"] = n
             roof["avg_launch_ms"] = round(ms / max(n, 1), 4)
             roof["algorithmic_gflop_per_launch"] = round(fl / max(n, 1) / 1e9, 3)
             roof["note"] = "fp32 peak 157.3 TFLOP/s is both the vector-FMA and the fp32-MFMA rate on gfx950"
-            roof["families_ms_per_step"] = {FAMILIES[f].split(" (")[0]: round(fam_stats[f][1] / args.steps, 3) for f in fam_stats}
-            roof["families_tflops"] = {FAMILIES[f].split(" (")[0]: round(fam_stats[f][2] / max(fam_stats[f][1], 1e-9) / 1e9, 2)
-                                       for f in fam_stats if fam_stats[f][2] > 0}
+            if warm_stats:  # whole-step breakdown from the profiled warm-up step (all families bracketed)
+                roof["families_ms_per_step_warmup"] = {FAMILIES[f].split(" (")[0]: round(warm_stats[f][1] / warm_steps, 3) for f in warm_stats}
+                roof["families_tflops_warmup"] = {FAMILIES[f].split(" (")[0]: round(warm_stats[f][2] / max(warm_stats[f][1], 1e-9) / 1e9, 2)
+                                                  for f in warm_stats if warm_stats[f][2] > 0}
+                roof["families_gbs_warmup"] = {FAMILIES[f].split(" (")[0]: round(warm_stats[f][3] / max(warm_stats[f][1], 1e-9) / 1e6, 1)
+                                               for f in warm_stats if warm_stats[f][3] > 0}
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

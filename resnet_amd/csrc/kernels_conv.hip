@@ -185,7 +185,7 @@ static int launch_dconv_t(hipStream_t st, dim3 grid, size_t lds, int tk, int jm,
 
 // one tap-kernel launch; ntr x ntc taps, weights already re-laid in wT
 static int launch_dconv(hipStream_t st, const float *in, const float *wT, float *out, const float *addend, DConvArgs a,
-                        int ntr, int ntc) {
+                        int ntr, int ntc, bool prof = true) {
     const int PIX = 448;
     a.total_pix = (uint32_t)a.N * a.Hsub * a.Wsub;
     a.PW = (a.Wsub - 1) * a.sx + ntc;
@@ -224,12 +224,12 @@ static int launch_dconv(hipStream_t st, const float *in, const float *wT, float 
     const double fl = 2.0 * ntr * ntc * (double)a.total_pix * a.Cin * a.Cout;
     const double by = 4.0 * ((double)a.N * a.Cin * a.Hin * a.Win / (a.osy * a.osx) + (double)ntr * ntc * a.Cin * a.Cout +
                              (double)a.total_pix * a.Cout * (addend ? 2 : 1));
-    mi_prof_begin(st, MI_FAM_DCONV, fl, by);
+    if (prof) mi_prof_begin(st, MI_FAM_DCONV, fl, by);
     int rc = -2;
 #define DC(NTR_, NTC_) if (ntr == NTR_ && ntc == NTC_) rc = launch_dconv_t<NTR_, NTC_>(st, grid, lds, tk, a.jcnt, in, wT, out, addend, a);
     DC(3, 3) DC(7, 7) DC(1, 1) DC(1, 2) DC(2, 1) DC(2, 2)
 #undef DC
-    mi_prof_end(st);
+    if (prof) mi_prof_end(st);
     if (rc) { mi_record_error("dconv", "unsupported tap shape"); return rc; }
     MI_LAUNCH_CHECK("dconv_kernel");
     return 0;
@@ -696,10 +696,24 @@ int mid_conv_dgrad(mid_stream s, mid_workspace *ws, const float *w, const float 
         a.Hsub = H; a.Wsub = H; a.osy = a.osx = 1; a.oy0 = a.ox0 = 0; a.sy = a.sx = 1; a.offy = a.offx = -1;
         return launch_dconv(st, dy, ws->wt, dx, addend, a, 3, 3);
     }
-    // stride 2: input pixel (2i+pa, 2j+pb); pa==0 -> r=1 (oh=i); pa==1 -> r=2 (oh=i), r=0 (oh=i+1)
+    // stride 2: input pixel (2i+pa, 2j+pb); pa==0 -> r=1 (oh=i); pa==1 -> r=2 (oh=i), r=0 (oh=i+1).
+    // The four parity classes write disjoint pixels, so they run CONCURRENTLY on four HIP streams (fork/join with
+    // events): the 1- and 2-tap classes fill the CUs the 4-tap class leaves idle in its tail.
+    static hipStream_t aux[3];
+    static hipEvent_t ev_fork, ev_join[3];
+    static int aux_ready = 0, use_aux = -1;
+    if (use_aux < 0) { const char *e = getenv("RESNET_MI_DGRAD_STREAMS"); use_aux = e ? atoi(e) : 1; }
+    if (use_aux && !aux_ready) {
+        for (int q = 0; q < 3; q++) { hipStreamCreateWithFlags(&aux[q], hipStreamNonBlocking); hipEventCreateWithFlags(&ev_join[q], hipEventDisableTiming); }
+        hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
+        aux_ready = 1;
+    }
     float *wt = ws->wt;
+    // weights of all four classes first (main stream), then fork
+    float *wts[4];
+    int cls = 0;
     for (int pa = 0; pa < 2; pa++)
-        for (int pb = 0; pb < 2; pb++) {
+        for (int pb = 0; pb < 2; pb++, cls++) {
             const int ntr = pa ? 2 : 1, ntc = pb ? 2 : 1;
             for (int tr = 0; tr < ntr; tr++)
                 for (int tc = 0; tc < ntc; tc++) {
@@ -707,12 +721,29 @@ int mid_conv_dgrad(mid_stream s, mid_workspace *ws, const float *w, const float 
                     src[tr * ntc + tc] = (unsigned char)(r * 3 + sc);
                 }
             if (launch_wt(st, w, wt, K, C, ntr * ntc, 3, C, 1, src)) return -1;
-            DConvArgs b = a;
-            b.Hsub = Ho; b.Wsub = Ho; b.osy = b.osx = 2; b.oy0 = pa; b.ox0 = pb; b.sy = b.sx = 1; b.offy = b.offx = 0;
-            int rc = launch_dconv(st, dy, wt, dx, addend, b, ntr, ntc);
-            if (rc) return rc;
+            wts[cls] = wt;
             wt += (size_t)ntr * ntc * C * K;
         }
+    // the four concurrent class kernels are timed as ONE launch of the dgrad operator (fork .. join on the main stream)
+    mi_prof_begin(st, MI_FAM_DCONV, 2.0 * 9 * (double)N * Ho * Ho * C * K,
+                  4.0 * ((double)N * K * Ho * Ho + 9.0 * C * K + (double)N * C * H * H * (addend ? 2 : 1)));
+    if (use_aux) {
+        hipEventRecord(ev_fork, st);
+        for (int q = 0; q < 3; q++) hipStreamWaitEvent(aux[q], ev_fork, 0);
+    }
+    cls = 0;
+    // heaviest class (2x2 taps) first on the main stream
+    for (int pa = 1; pa >= 0; pa--)
+        for (int pb = 1; pb >= 0; pb--, cls++) {
+            const int ntr = pa ? 2 : 1, ntc = pb ? 2 : 1;
+            hipStream_t sq = (use_aux && cls > 0) ? aux[cls - 1] : st;
+            DConvArgs b = a;
+            b.Hsub = Ho; b.Wsub = Ho; b.osy = b.osx = 2; b.oy0 = pa; b.ox0 = pb; b.sy = b.sx = 1; b.offy = b.offx = 0;
+            int rc = launch_dconv(sq, dy, wts[pa * 2 + pb], dx, addend, b, ntr, ntc, false);
+            if (rc) return rc;
+            if (use_aux && cls > 0) { hipEventRecord(ev_join[cls - 1], sq); hipStreamWaitEvent(st, ev_join[cls - 1], 0); }
+        }
+    mi_prof_end(st);
     return 0;
 }
 

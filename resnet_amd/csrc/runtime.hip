@@ -92,7 +92,7 @@ static void prof_resolve(void) {
     P.n = 0;
 }
 void mi_prof_begin(hipStream_t st, int fam, double flops, double bytes) {
-    if (!P.on) return;
+    if (!(P.on & (1 << fam))) return;
     if (P.n == PROF_MAX) prof_resolve();
     const int i = P.n;
     if (i >= P.created) { HIPCHK(hipEventCreate(&P.a[i])); HIPCHK(hipEventCreate(&P.b[i])); P.created = i + 1; }
@@ -106,7 +106,7 @@ void mi_prof_end(hipStream_t st) {
     P.n++; P.open = 0;
 }
 extern "C" {
-void mid_prof_enable(int on) { P.on = on; }
+void mid_prof_enable(int on) { P.on = on == 1 ? 0xff : on; } /* 1 = all families, else a bit mask (1 << family) */
 void mid_prof_reset(void) {
     prof_resolve();
     for (int f = 0; f < MI_FAM_COUNT; f++) { P.launches[f] = 0; P.ms[f] = P.flops[f] = P.bytes[f] = 0; }
