@@ -704,8 +704,8 @@ int mid_conv_dgrad(mid_stream s, mid_workspace *ws, const float *w, const float 
     static int aux_ready = 0, use_aux = -1;
     if (use_aux < 0) { const char *e = getenv("RESNET_MI_DGRAD_STREAMS"); use_aux = e ? atoi(e) : 1; }
     if (use_aux && !aux_ready) {
-        for (int q = 0; q < 3; q++) { hipStreamCreateWithFlags(&aux[q], hipStreamNonBlocking); hipEventCreateWithFlags(&ev_join[q], hipEventDisableTiming); }
-        hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
+        for (int q = 0; q < 3; q++) { (void)hipStreamCreateWithFlags(&aux[q], hipStreamNonBlocking); (void)hipEventCreateWithFlags(&ev_join[q], hipEventDisableTiming); }
+        (void)hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
         aux_ready = 1;
     }
     float *wt = ws->wt;
@@ -728,8 +728,8 @@ int mid_conv_dgrad(mid_stream s, mid_workspace *ws, const float *w, const float 
     mi_prof_begin(st, MI_FAM_DCONV, 2.0 * 9 * (double)N * Ho * Ho * C * K,
                   4.0 * ((double)N * K * Ho * Ho + 9.0 * C * K + (double)N * C * H * H * (addend ? 2 : 1)));
     if (use_aux) {
-        hipEventRecord(ev_fork, st);
-        for (int q = 0; q < 3; q++) hipStreamWaitEvent(aux[q], ev_fork, 0);
+        (void)hipEventRecord(ev_fork, st);
+        for (int q = 0; q < 3; q++) (void)hipStreamWaitEvent(aux[q], ev_fork, 0);
     }
     cls = 0;
     // heaviest class (2x2 taps) first on the main stream
@@ -741,7 +741,7 @@ int mid_conv_dgrad(mid_stream s, mid_workspace *ws, const float *w, const float 
             b.Hsub = Ho; b.Wsub = Ho; b.osy = b.osx = 2; b.oy0 = pa; b.ox0 = pb; b.sy = b.sx = 1; b.offy = b.offx = 0;
             int rc = launch_dconv(sq, dy, wts[pa * 2 + pb], dx, addend, b, ntr, ntc, false);
             if (rc) return rc;
-            if (use_aux && cls > 0) { hipEventRecord(ev_join[cls - 1], sq); hipStreamWaitEvent(st, ev_join[cls - 1], 0); }
+            if (use_aux && cls > 0) { (void)hipEventRecord(ev_join[cls - 1], sq); (void)hipStreamWaitEvent(st, ev_join[cls - 1], 0); }
         }
     mi_prof_end(st);
     return 0;
