@@ -226,6 +226,8 @@ enum { MI_SRC_SHARDS = 0, MI_SRC_BUFFER = 1, MI_SRC_SYNTHETIC = 2, MI_SRC_HOST =
 enum { MI_LAYOUT_NHWC = 0, MI_LAYOUT_NCHW = 1 };
 /* shards: <dir>/%03d.images + %03d.labels (build_training_shards.c:150-160 / resnet.cu:1275-1285) */
 void mi_batch_source_shards(Batch *b, const char *shard_dir, int layout);
+/* overlap the H2D copy of batch t+1 with step t (copy stream, pinned double buffer); shard source only */
+void mi_batch_set_prefetch(Batch *b, int on);
 /* one dumped batch: images.buffer / labels.buffer (resnet.cu:1301-1311) */
 void mi_batch_source_buffer(Batch *b, const char *images_path, const char *labels_path, int layout);
 /* seeded synthetic stream kept resident in HBM: images U(-124,152), labels uniform */

@@ -122,6 +122,7 @@ PROTOTYPES = {
     "mi_device_synchronize": (None, []),
     "destroy_trainer": (None, [_T]),
     "mi_batch_source_shards": (None, [_B, _cp, _i]),
+    "mi_batch_set_prefetch": (None, [_B, _i]),
     "mi_batch_source_buffer": (None, [_B, _cp, _cp, _i]),
     "mi_batch_source_synthetic": (None, [_B, _u64, _u64, _i, _i]),
     "mi_batch_source_host": (None, [_B, _i]),

@@ -30,6 +30,9 @@ void mi_batch_ext_free(Batch *b) {
         *pp = e->next;
         free(e->shard_dir); free(e->images_path); free(e->labels_path);
         mid_free(e->pool_images); mid_free(e->pool_labels); mid_free(e->stage_dev); free(e->pool_labels_host);
+        mid_free(e->images_next); mid_free(e->stage_next); mid_free(e->labels_next);
+        mid_free_host(e->pinned_next); mid_free_host(e->labels_next_host);
+        if (e->ev_next) mid_event_destroy(e->ev_next);
         free(e);
     }
     mid_free_host(b->images_float_cpu); mid_free_host(b->correct_classes_cpu);
@@ -55,6 +58,37 @@ static void set_str(char **dst, const char *s) { free(*dst); *dst = s ? strdup(s
 void mi_batch_source_shards(Batch *b, const char *dir, int layout) {
     BatchExt *e = mi_batch_ext(b);
     e->source = MI_SRC_SHARDS; e->layout = layout; set_str(&e->shard_dir, dir);
+    e->have_next = 0;
+}
+/* double-buffered H2D: while step t runs, batch t+1 of the resident shard goes pinned -> device on the copy stream
+ * (the reference copies synchronously at the top of every step, resnet.cu:1315-1316) */
+void mi_batch_set_prefetch(Batch *b, int on) {
+    BatchExt *e = mi_batch_ext(b);
+    e->prefetch = on; e->have_next = 0;
+    if (on && !e->images_next) {
+        const size_t bytes = (size_t)b->n_images * b->image_size * sizeof(float);
+        e->images_next = (float *)mid_malloc(bytes);
+        e->stage_next = (float *)mid_malloc(bytes);
+        e->pinned_next = (float *)mid_malloc_host(bytes);
+        e->labels_next = (int *)mid_malloc((size_t)b->n_images * sizeof(int));
+        e->labels_next_host = (int *)mid_malloc_host((size_t)b->n_images * sizeof(int));
+        e->ev_next = mid_event_create();
+    }
+}
+/* enqueue batch (shard resident in host RAM, index bi) on the copy stream into the *_next buffers */
+static void prefetch_enqueue(Batch *b, BatchExt *e, int bi) {
+    MiGlobal *g = mi_global();
+    const int N = b->n_images;
+    const size_t px = (size_t)N * b->image_size, bytes = px * sizeof(float);
+    memcpy(e->pinned_next, b->full_shard_images + (size_t)bi * px, bytes);
+    memcpy(e->labels_next_host, b->full_shard_correct_classes + (size_t)bi * N, (size_t)N * sizeof(int));
+    if (e->layout == MI_LAYOUT_NHWC) {
+        mid_memcpy_h2d(e->stage_next, e->pinned_next, bytes, g->copy);
+        mid_nhwc_to_nchw(g->copy, e->stage_next, e->images_next, N, b->image_dim, b->image_dim, b->image_size / (b->image_dim * b->image_dim));
+    } else mid_memcpy_h2d(e->images_next, e->pinned_next, bytes, g->copy);
+    mid_memcpy_h2d(e->labels_next, e->labels_next_host, (size_t)N * sizeof(int), g->copy);
+    mid_event_record(e->ev_next, g->copy);
+    e->have_next = 1; e->next_shard_id = b->cur_shard_id; e->next_batch_in_shard = bi;
 }
 void mi_batch_source_buffer(Batch *b, const char *images_path, const char *labels_path, int layout) {
     BatchExt *e = mi_batch_ext(b);
@@ -140,9 +174,24 @@ void load_new_batch(Train_ResNet *trainer, Class_Metadata *class_metadata, Batch
             trainer->init_loaded = 0;
         }
         if (e->status == 0) {
-            memcpy(b->images_float_cpu, b->full_shard_images + (size_t)b->cur_batch_in_shard * total_pixels, total_pixels * sizeof(float));
-            memcpy(b->correct_classes_cpu, b->full_shard_correct_classes + (size_t)b->cur_batch_in_shard * N, (size_t)N * sizeof(int));
-            upload(b, e);
+            if (e->prefetch && e->have_next && e->next_shard_id == b->cur_shard_id && e->next_batch_in_shard == b->cur_batch_in_shard) {
+                /* batch already on the device: order the compute stream after the copy and swap buffers */
+                mid_stream_wait_event(g->compute, e->ev_next);
+                mid_event_sync(e->ev_next); /* the pinned staging buffer is rewritten below */
+                float *ti = b->images; b->images = e->images_next; e->images_next = ti;
+                int *tl = b->correct_classes; b->correct_classes = e->labels_next; e->labels_next = tl;
+                memcpy(b->correct_classes_cpu, e->labels_next_host, (size_t)N * sizeof(int));
+                e->have_next = 0;
+            } else {
+                memcpy(b->images_float_cpu, b->full_shard_images + (size_t)b->cur_batch_in_shard * total_pixels, total_pixels * sizeof(float));
+                memcpy(b->correct_classes_cpu, b->full_shard_correct_classes + (size_t)b->cur_batch_in_shard * N, (size_t)N * sizeof(int));
+                upload(b, e);
+            }
+            if (e->prefetch && (b->cur_batch_in_shard + 2) * N <= b->shard_n_images) {
+                /* the swapped-out buffer may still be read by the step that just ended: that step was synchronised by
+                 * update_parameters / forward_pass before the caller got here, so the copy stream can reuse it */
+                prefetch_enqueue(b, e, b->cur_batch_in_shard + 1);
+            }
         }
     } else if (e->source == MI_SRC_BUFFER) {
         if (!e->pool_next) {

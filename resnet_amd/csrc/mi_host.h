@@ -31,6 +31,11 @@ typedef struct BatchExt {
     int *pool_labels;   /* device */
     int *pool_labels_host;
     float *stage_dev;   /* device staging for NHWC -> NCHW */
+    /* shard prefetch: batch t+1 is copied to the device on the copy stream while step t computes */
+    int prefetch, have_next, next_shard_id, next_batch_in_shard;
+    float *images_next, *stage_next, *pinned_next;
+    int *labels_next, *labels_next_host;
+    mid_event ev_next;
     uint64_t synth_step;
     struct BatchExt *next;
 } BatchExt;

@@ -97,8 +97,10 @@ class Trainer:
     def source_buffer(self, images_path, labels_path, layout=B.MI_LAYOUT_NHWC):
         self.L.mi_batch_source_buffer(self.c_batch, images_path.encode(), labels_path.encode(), layout)
 
-    def source_shards(self, shard_dir, layout=B.MI_LAYOUT_NCHW):
+    def source_shards(self, shard_dir, layout=B.MI_LAYOUT_NCHW, prefetch=False):
         self.L.mi_batch_source_shards(self.c_batch, shard_dir.encode(), layout)
+        if prefetch:
+            self.L.mi_batch_set_prefetch(self.c_batch, 1)
 
     def fill_host_batch(self, images, labels):
         """write the caller-owned pinned staging buffers (images_float_cpu / correct_classes_cpu)"""

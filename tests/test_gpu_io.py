@@ -43,8 +43,9 @@ def test_images_buffer_labels_buffer(tmp_path):
     tr.close()
 
 
+@pytest.mark.parametrize("prefetch", [False, True])
 @pytest.mark.parametrize("layout", ["nchw", "nhwc"])
-def test_shard_rotation(tmp_path, layout):
+def test_shard_rotation(tmp_path, layout, prefetch):
     """%03d.images / %03d.labels shards (build_training_shards.c:150-160): whole shard in host RAM, batches in order,
     next shard when the current one is exhausted (resnet.cu:1266-1295); a missing shard is reported, not dereferenced"""
     from resnet_amd import binding as B
@@ -56,7 +57,7 @@ def test_shard_rotation(tmp_path, layout):
         lab.tofile(tmp_path / ("%03d.labels" % sid))
         shards.append((im, lab))
     tr = _trainer(batch, shard_n_images=per_shard)
-    tr.source_shards(str(tmp_path), B.MI_LAYOUT_NCHW if layout == "nchw" else B.MI_LAYOUT_NHWC)
+    tr.source_shards(str(tmp_path), B.MI_LAYOUT_NCHW if layout == "nchw" else B.MI_LAYOUT_NHWC, prefetch=prefetch)
     for step in range(4):
         tr.load_new_batch()
         assert tr.L.mi_batch_last_status(tr.c_batch) == 0
@@ -66,6 +67,8 @@ def test_shard_rotation(tmp_path, layout):
         assert np.array_equal(tr.labels(), lab[b * batch:(b + 1) * batch])
         assert tr.c_batch.contents.cur_shard_id == sid
         assert tr.t.contents.cur_dump_id == step  # ++cur_dump_id per load (resnet.cu:1322)
+        if prefetch:  # a full step between loads, as in training: the next batch is copied underneath it
+            tr.forward(); tr.backward(); tr.update()
     tr.load_new_batch()  # shard 002 does not exist
     assert tr.L.mi_batch_last_status(tr.c_batch) == -1
     tr.close()
