@@ -1,0 +1,143 @@
+"""Size-independent properties at BASELINE.json's full sizes (the oracle needs minutes there, so it is not the checker):
+the reference-defined ResNet-50, fp32, 224x224, batch 256, and the network's own layer shapes at large batch.
+  * adjoint identities  <conv(x,w), dy> = <x, dgrad(w,dy)> = <w, wgrad(x,dy)>  tie the three conv kernels together
+  * exact fp32 homogeneity  conv(x, 2w) == 2 conv(x, w)  (bitwise)
+  * BN statistics recomputed in float64 from the full tensor; soft-max rows sum to 1; ReLU outputs >= 0
+  * max-pool: every stored arg-max lies in its window and holds the pooled value
+  * directional finite differences of the batch-sum loss against the analytic gradients (layers after the max-pool;
+    the reference's overwrite max-pool backward is not the exact gradient, so the stem is excluded)
+  * bitwise run-to-run determinism; Adam's first step moves every weight by at most lr; gradients zeroed afterwards
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev_uniform(ops, shape, seed, lo, hi):
+    d = ops.dev(shape=shape)
+    assert ops.L.mi_op_fill_uniform(d.ptr, int(np.prod(shape)), seed, lo, hi) == 0
+    return d
+
+
+# (C, H, K, k, stride): every distinct heavy layer type of the reference ResNet-50, batch 32
+ADJ_SHAPES = [(64, 56, 64, 3, 1), (256, 56, 512, 3, 2), (128, 28, 128, 3, 1), (512, 28, 1024, 3, 2), (256, 14, 256, 3, 1),
+              (1024, 14, 2048, 3, 2), (512, 7, 512, 3, 1), (256, 56, 64, 1, 1), (512, 7, 2048, 1, 1), (1024, 14, 256, 1, 1)]
+
+
+@pytest.mark.parametrize("shape", ADJ_SHAPES, ids=["C%d_H%d_K%d_k%d_s%d" % s for s in ADJ_SHAPES])
+def test_conv_adjoint_identities_and_homogeneity(ops, shape):
+    Cc, H, K, k, s = shape
+    N, Ho = 32, H // s
+    L = ops.L
+    x = _dev_uniform(ops, (N, Cc, H, H), 11, -1.0, 1.0)
+    w = _dev_uniform(ops, (K, Cc, k, k), 12, -0.05, 0.05)
+    dy = _dev_uniform(ops, (N, K, Ho, Ho), 13, -1.0, 1.0)
+    y, dx, dw = ops.dev(shape=(N, K, Ho, Ho)), ops.dev(shape=(N, Cc, H, H)), ops.dev(shape=(K, Cc, k, k))
+    assert L.mi_op_conv_fwd(x.ptr, w.ptr, y.ptr, N, Cc, H, K, k, s) == 0, L.mi_last_error()
+    assert L.mi_op_conv_dgrad(w.ptr, dy.ptr, dx.ptr, N, Cc, H, K, k, s, 0) == 0, L.mi_last_error()
+    assert L.mi_op_conv_wgrad(x.ptr, dy.ptr, dw.ptr, N, Cc, H, K, k, s) == 0, L.mi_last_error()
+    hx, hw, hdy = x.get().astype(np.float64), w.get(), dy.get().astype(np.float64)
+    hy = y.get()
+    a = float(np.vdot(hy.astype(np.float64), hdy))
+    b = float(np.vdot(hx, dx.get().astype(np.float64)))
+    c = float(np.vdot(hw.astype(np.float64), dw.get().astype(np.float64)))
+    scale = float(np.linalg.norm(hy.astype(np.float64)) * np.linalg.norm(hdy))
+    assert abs(a - b) <= 2e-6 * scale and abs(a - c) <= 2e-6 * scale, (a, b, c, scale)
+    # fp32 homogeneity: scaling the weights by 2 is exact in every product and every partial sum
+    w2 = ops.dev((2.0 * hw).astype(np.float32))
+    y2 = ops.dev(shape=(N, K, Ho, Ho))
+    assert L.mi_op_conv_fwd(x.ptr, w2.ptr, y2.ptr, N, Cc, H, K, k, s) == 0
+    assert np.array_equal(y2.get(), 2.0 * hy)
+
+
+@pytest.fixture(scope="module")
+def r50():
+    from resnet_amd import Trainer
+    tr = Trainer(synth.R50_DIMS, 256, lr=1e-4, seed=1236)
+    if tr.L.mi_device_count() < 1:
+        pytest.fail("needs the MI355X box")
+    tr.source_synthetic(1234, 1235, pool_batches=1)
+    tr.L.mi_trainer_set_input_reset(tr.t, 0)
+    yield tr
+    tr.close()
+
+
+def _loss64(tr):
+    p = tr.pred().astype(np.float64)
+    return float(-np.log(p[np.arange(p.shape[0]), tr.labels()]).sum())
+
+
+def test_fullsize_forward_properties(r50):
+    tr = r50
+    tr.load_new_batch(); tr.forward(); tr.check()
+    p = tr.pred()
+    assert np.all(np.isfinite(p)) and np.allclose(p.sum(axis=1), 1.0, atol=1e-5)
+    assert abs(tr.loss()[0] - _loss64(tr)) <= 1e-3 * 256
+    for name in ("conv_blocks/05/spatial_applied", "conv_blocks/13/transformed_residual", "init_conv_applied"):
+        x = tr.activation(name).astype(np.float64)
+        bn = {"conv_blocks/05/spatial_applied": "batch_norms/05/spatial", "conv_blocks/13/transformed_residual": "batch_norms/13/projected",
+              "init_conv_applied": "batch_norms/init"}[name]
+        m, v = tr.activation(bn + "/means"), tr.activation(bn + "/vars")
+        rm, rv = x.mean(axis=(0, 2, 3)), x.var(axis=(0, 2, 3))  # biased variance, as resnet.cu:321
+        assert np.allclose(m, rm, rtol=1e-5, atol=1e-6 * np.abs(rm).max()), name
+        assert np.allclose(v, rv, rtol=2e-5), name
+    for b in (0, 3, 15):
+        assert tr.activation("conv_blocks/%02d/output_activated" % b).min() >= 0.0
+    # max-pool: arg-max inside the 3x3/s2 window centred at 2*o and holding the pooled value
+    xin, idx, y = tr.activation("init_conv_activated"), tr.activation("max_inds"), tr.activation("init_convblock_input")
+    assert np.array_equal(xin.ravel()[idx.ravel()], y.ravel())
+    N, Cc, Ho, _ = y.shape
+    H = xin.shape[2]
+    pos = idx - (np.arange(N)[:, None, None, None] * Cc + np.arange(Cc)[None, :, None, None]) * H * H
+    ih, iw = pos // H, pos % H
+    oh, ow = np.arange(Ho)[None, None, :, None], np.arange(Ho)[None, None, None, :]
+    assert np.all(np.abs(ih - 2 * oh) <= 1) and np.all(np.abs(iw - 2 * ow) <= 1)
+
+
+def test_fullsize_gradient_finite_differences_and_determinism(r50):
+    tr = r50
+    tr.load_new_batch(); tr.forward(); tr.backward(); tr.check()
+    n_loc = tr.n_locations
+    grads_a = {i: tr.get("grads", i) for i in (n_loc - 1, n_loc - 4, 30, 5)}
+    # determinism: the same step again gives bit-identical gradients (no atomics, fixed reduction orders)
+    tr.L.mi_copy_to_device  # (gradients are overwritten by every backward; Adam has not run)
+    tr.forward(); tr.backward()
+    for i, g in grads_a.items():
+        assert np.array_equal(tr.get("grads", i), g), "location %d not reproducible" % i
+    # directional finite differences of L = -sum log p[label] along the gradient direction
+    for i in (n_loc - 1, n_loc - 4, 30, 5):  # FC, last expansion conv, a mid conv, block-0 reduce-BN beta
+        g = grads_a[i].astype(np.float64)
+        gn = np.linalg.norm(g)
+        assert gn > 0
+        theta = tr.get("params", i)
+        # expected |dL| = 2*eps*|g| on a loss of ~1.8e3: above fp32 noise (~2e-3); the early layer sits under 50 ReLU/BN
+        # layers (strong curvature), so it takes a smaller step and a wider band
+        eps = (0.5 if i > 20 else 0.1) / gn
+        v = g / gn
+        losses = []
+        for sgn in (+1, -1):
+            tr.set("params", i, (theta.astype(np.float64) + sgn * eps * v).astype(np.float32))
+            tr.forward()
+            losses.append(_loss64(tr))
+        tr.set("params", i, theta)
+        fd = (losses[0] - losses[1]) / (2 * eps)
+        assert abs(fd - gn) <= (0.03 if i > 20 else 0.06) * gn, "location %d: finite difference %.5g vs |grad| %.5g" % (i, fd, gn)
+
+
+def test_fullsize_adam_step(r50):
+    tr = r50
+    tr.load_new_batch(); tr.forward(); tr.backward()
+    before = {i: tr.get("params", i) for i in (0, 30, tr.n_locations - 1)}
+    tr.update(); tr.check()
+    for i, b in before.items():
+        d = np.abs(tr.get("params", i) - b)
+        assert d.max() <= 1e-4 * 1.001 + 1e-9, i      # first bias-corrected step is lr * g/(|g|+eps)
+        assert np.count_nonzero(d) > 0.5 * d.size
+        assert not np.any(tr.get("grads", i))
+    tr.load_new_batch(); tr.forward()
+    assert np.isfinite(tr.loss()[0])
