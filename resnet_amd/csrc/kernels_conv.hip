@@ -84,16 +84,18 @@ dconv_kernel(const float *__restrict__ in, const float *__restrict__ wT, float *
     const int lbase = ((int)(n * a.Hq + i * a.sy) - q0) * a.PW + j * a.sx;
     __syncthreads();
     // patch positions this thread stages: pos = tid + 448*jj  ->  element offset inside channel 0 (or -1 = zero)
-    int goff[JM];
+    // byte offsets (unsigned, so a load is scalar channel base + 32-bit lane offset: no 64-bit VALU address math);
+    // invalid positions (halo, tail) point at element 0 and are zeroed by the validity bit when stashed
+    uint32_t goff[JM], gvalid = 0;
 #pragma unroll
     for (int jj = 0; jj < JM; jj++) {
         const int pos = tid + jj * 448;
-        int g = -1;
+        uint32_t g = 0;
         if (jj < a.jcnt && pos < plane) {
             const uint32_t qr = fd_div((uint32_t)pos, a.fd_PW);
             const int iw = pos - (int)qr * a.PW + a.offx;
             const int t = tbl[qr];
-            if (t >= 0 && iw >= 0 && iw < a.Win) g = t + iw;
+            if (t >= 0 && iw >= 0 && iw < a.Win) { g = (uint32_t)(t + iw) * 4u; gvalid |= 1u << jj; }
         }
         goff[jj] = g;
     }
@@ -102,13 +104,9 @@ dconv_kernel(const float *__restrict__ in, const float *__restrict__ wT, float *
 #pragma unroll
         for (int c = 0; c < CCM; c++) {
             const bool cok = c < a.CC && c0 + c < a.Cin;
-            const float *src = in + (size_t)(c0 + c) * HW;
+            const char *src = (const char *)(in + (size_t)(cok ? c0 + c : 0) * HW); // wave-uniform
 #pragma unroll
-            for (int jj = 0; jj < JM; jj++) {
-                float v = 0.f;
-                if (cok && goff[jj] >= 0) v = src[goff[jj]];
-                regs[c][jj] = v;
-            }
+            for (int jj = 0; jj < JM; jj++) regs[c][jj] = *(const float *)(src + goff[jj]); // masked when stashed
         }
     };
     auto stash = [&](float *buf) {
@@ -118,7 +116,7 @@ dconv_kernel(const float *__restrict__ in, const float *__restrict__ wT, float *
 #pragma unroll
                 for (int jj = 0; jj < JM; jj++) {
                     const int pos = tid + jj * 448;
-                    if (jj < a.jcnt && pos < plane) buf[c * plane + pos] = regs[c][jj];
+                    if (jj < a.jcnt && pos < plane) buf[c * plane + pos] = ((gvalid >> jj) & 1u) ? regs[c][jj] : 0.f;
                 }
             }
         }
