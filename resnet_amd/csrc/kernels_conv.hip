@@ -405,8 +405,7 @@ __global__ void __launch_bounds__(256)
 wgradC_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ part, const WcArgs a) {
     constexpr int NXW = 3 * S + 3;
     extern __shared__ float sm[];
-    float *xsm = sm;                 // [64][pitch] + slack
-    float *dys = sm + a.xs_floats;   // [32][DP]
+    // per buffer: x patch [64][pitch] + slack (xs_floats), then the dY tile [pixel slot][WC_DPK]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kb0 = blockIdx.x * 32, cb = blockIdx.y * 64;
@@ -420,7 +419,7 @@ wgradC_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *
         for (int kp = 0; kp < 4; kp++) acc[t][kp] = (f32x2){0.f, 0.f};
     // masked tail columns of a row read past the patch row (next row / pitch pad / slack) and multiply it by dY = 0:
     // everything they can touch must be finite, so the whole x region starts zeroed (pads are never rewritten)
-    for (int i = tid; i < a.xs_floats; i += 256) xsm[i] = 0.f;
+    for (int i = tid; i < 2 * (a.xs_floats + 32 * WC_DPK); i += 256) sm[i] = 0.f;
     // x staging: wave w stages channels w*16 .. w*16+15; lane l owns patch positions l and l+64 (row, col fixed for
     // the whole kernel), so a slot costs one scalar channel base + one per-lane constant offset
     float pre[2][16], pred[4];
@@ -473,8 +472,11 @@ wgradC_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *
             pred[j] = v;
         }
     };
-    auto stash = [&]() {
-        float *xw_ = xsm + wave * 16 * a.pitch + lane;
+    // two LDS buffers (x patch + dY tile each): chunk ch+1 is stashed while other waves may still multiply chunk ch,
+    // so there is ONE barrier per chunk (occupancy is VGPR-limited to 2 workgroups/CU, the second buffer is free)
+    const int bufsz = a.xs_floats + 32 * WC_DPK;
+    auto stash = [&](float *base) {
+        float *xw_ = base + wave * 16 * a.pitch + lane;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             if (lane + 64 * h < patch) {
@@ -483,21 +485,25 @@ wgradC_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *
             }
         }
         if (dslot) {
+            float *dd = base + a.xs_floats;
 #pragma unroll
-            for (int j = 0; j < 4; j++) dys[ps * WC_DPK + (tid >> 5) + 8 * j] = pred[j];
+            for (int j = 0; j < 4; j++) dd[ps * WC_DPK + (tid >> 5) + 8 * j] = pred[j];
         }
     };
 
     const int ch_beg = blockIdx.z * a.chunks_per_split;
     const int ch_end = min(a.chunks_total, ch_beg + a.chunks_per_split);
     if (ch_beg < ch_end) issue(ch_beg);
-    const float *xl = xsm + lane * a.pitch;
-    const float *dw = dys + wave * 8;
+    __syncthreads(); // zero fill above is complete
+    if (ch_beg < ch_end) {
+        stash(sm);
+        if (ch_beg + 1 < ch_end) issue(ch_beg + 1);
+    }
+    __syncthreads();
     for (int ch = ch_beg; ch < ch_end; ch++) {
-        __syncthreads();
-        stash();
-        __syncthreads();
-        if (ch + 1 < ch_end) issue(ch + 1);
+        const float *cur = sm + ((ch - ch_beg) & 1) * bufsz;
+        const float *xl = cur + lane * a.pitch;
+        const float *dw = cur + a.xs_floats + wave * 8;
         for (int r = 0; r < a.rows; r++) {
             for (int q = 0; q < a.QPR; q++) {
                 float xw[3][NXW];
@@ -524,6 +530,11 @@ wgradC_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *
                 }
             }
         }
+        if (ch + 1 < ch_end) {
+            stash(sm + ((ch + 1 - ch_beg) & 1) * bufsz);
+            if (ch + 2 < ch_end) issue(ch + 2);
+        }
+        __syncthreads();
     }
     float *po = part + (size_t)blockIdx.z * a.part_stride;
     const int kb = kb0 + wave * 8;
@@ -764,7 +775,7 @@ int mid_conv_wgrad(mid_stream s, mid_workspace *ws, const float *x, const float 
         b.part_stride = wsz9;
         float *outp = pb.splits == 1 ? dw : ws->part;
         dim3 grid(K / 32, C / 64, pb.splits);
-        const size_t lds = (size_t)(b.xs_floats + 32 * WC_DPK) * 4;
+        const size_t lds = (size_t)2 * (b.xs_floats + 32 * WC_DPK) * 4;
         mi_prof_begin(st, MI_FAM_WGRAD, 2.0 * 9 * (double)N * b.Ho * b.Wo * C * K,
                       4.0 * ((double)N * C * H * H + (double)N * K * b.Ho * b.Wo + 9.0 * C * K));
         if (stride == 1) hipLaunchKernelGGL((wgradC_kernel<1>), grid, dim3(256), lds, st, x, dy, outp, b);
