@@ -66,110 +66,79 @@ gemm_mfma_kernel(const float *__restrict__ A, const float *__restrict__ B, float
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    // element offset of (row-ish index, kk) for each operand; `row` is m (A) or n (B)
-    auto a_addr = [&](int i, int kk) -> long {
-        long off = (long)(m0 + i) * g.a_sm;
-        if (BATCH == BATCH_K) { const uint32_t n = fd_div((uint32_t)kk, g.fdP); off += (long)n * g.a_sb + (kk - (long)n * g.P); }
-        else off += (long)kk * g.a_sk;
-        return off;
+    // Per-thread staging coordinates and the kk-independent part of every element offset, computed ONCE:
+    // inside the k loop an address costs one multiply-add (plus one fast division per k-step when K is the batched dim).
+    constexpr int NA = VA ? AV : AE, NB = VB ? BV : BE;
+    int ai[NA], ak[NA], bj[NB], bk[NB];
+    long aoff[NA], boff[NB];
+#pragma unroll
+    for (int q = 0; q < NA; q++) {
+        if (VA) {
+            if (A_KC) { ak[q] = (tid & 7) * 4; ai[q] = (tid >> 3) + 32 * q; }
+            else { ai[q] = (tid & (BM / 4 - 1)) * 4; ak[q] = tid / (BM / 4) + (1024 / BM) * q; }
+        } else {
+            if (A_KC) { ak[q] = tid & 31; ai[q] = (tid >> 5) + 8 * q; }
+            else { ai[q] = tid % BM; ak[q] = tid / BM + (256 / BM) * q; }
+        }
+        aoff[q] = (long)(m0 + ai[q]) * g.a_sm;
+    }
+#pragma unroll
+    for (int q = 0; q < NB; q++) {
+        if (VB) {
+            if (B_KC) { bk[q] = (tid & 7) * 4; bj[q] = (tid >> 3) + 32 * q; }
+            else { bj[q] = (tid & 31) * 4; bk[q] = (tid >> 5) + 8 * q; }
+        } else {
+            if (B_KC) { bk[q] = tid & 31; bj[q] = (tid >> 5) + 8 * q; }
+            else { bj[q] = tid & 127; bk[q] = (tid >> 7) + 2 * q; }
+        }
+        const int col = min(n0 + bj[q], g.N - 1);
+        if (BATCH == BATCH_N) { const uint32_t n = fd_div((uint32_t)col, g.fdP); boff[q] = (long)n * g.b_sb + (col - (long)n * g.P); }
+        else boff[q] = (long)col * g.b_sn;
+    }
+    // kk-dependent part (batched K: the reduction index is (image, pixel))
+    auto koff_a = [&](int kk) -> long {
+        if (BATCH == BATCH_K) { const uint32_t n = fd_div((uint32_t)kk, g.fdP); return (long)n * g.a_sb + (kk - (long)n * g.P); }
+        return (long)kk * g.a_sk;
     };
-    auto b_addr = [&](int j, int kk) -> long {
-        const int col = n0 + j;
-        long off;
-        if (BATCH == BATCH_N) { const uint32_t n = fd_div((uint32_t)col, g.fdP); off = (long)n * g.b_sb + (col - (long)n * g.P) + (long)kk * g.b_sk; }
-        else if (BATCH == BATCH_K) { const uint32_t n = fd_div((uint32_t)kk, g.fdP); off = (long)col * g.b_sn + (long)n * g.b_sb + (kk - (long)n * g.P); }
-        else off = (long)col * g.b_sn + (long)kk * g.b_sk;
-        return off;
+    auto koff_b = [&](int kk) -> long {
+        if (BATCH == BATCH_K) { const uint32_t n = fd_div((uint32_t)kk, g.fdP); return (long)n * g.b_sb + (kk - (long)n * g.P); }
+        return (long)kk * g.b_sk;
     };
 
     gf4 ra4[VA ? AV : 1], rb4[VB ? BV : 1];
     float ra[VA ? 1 : AE], rb[VB ? 1 : BE];
     auto load_tile = [&](int k0) {
-        if (VA) {
 #pragma unroll
-            for (int q = 0; q < AV; q++) {
-                int i, kk;
-                if (A_KC) { kk = (tid & 7) * 4; i = (tid >> 3) + 32 * q; }
-                else { i = (tid & (BM / 4 - 1)) * 4; kk = tid / (BM / 4) + (1024 / BM) * q; }
-                gf4 v = {0.f, 0.f, 0.f, 0.f};
-                if (m0 + i < g.M && k0 + kk < kend) v = *(const gf4 *)(A + a_addr(i, k0 + kk));
-                ra4[q] = v;
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < AE; q++) {
-                int i, kk;
-                if (A_KC) { kk = tid & 31; i = (tid >> 5) + 8 * q; }
-                else { i = tid % BM; kk = tid / BM + (256 / BM) * q; }
-                float v = 0.f;
-                if (m0 + i < g.M && k0 + kk < kend) v = A[a_addr(i, k0 + kk)];
-                ra[q] = v;
-            }
+        for (int q = 0; q < NA; q++) {
+            const int kk = k0 + ak[q];
+            const bool ok = m0 + ai[q] < g.M && kk < kend;
+            if (VA) { gf4 v = {0.f, 0.f, 0.f, 0.f}; if (ok) v = *(const gf4 *)(A + aoff[q] + koff_a(kk)); ra4[q] = v; }
+            else { float v = 0.f; if (ok) v = A[aoff[q] + koff_a(kk)]; ra[q] = v; }
         }
-        if (VB) {
 #pragma unroll
-            for (int q = 0; q < BV; q++) {
-                int j, kk;
-                if (B_KC) { kk = (tid & 7) * 4; j = (tid >> 3) + 32 * q; }
-                else { j = (tid & 31) * 4; kk = (tid >> 5) + 8 * q; }
-                gf4 v = {0.f, 0.f, 0.f, 0.f};
-                if (n0 + j < g.N && k0 + kk < kend) v = *(const gf4 *)(B + b_addr(j, k0 + kk));
-                rb4[q] = v;
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < BE; q++) {
-                int j, kk;
-                if (B_KC) { kk = tid & 31; j = (tid >> 5) + 8 * q; }
-                else { j = tid & 127; kk = (tid >> 7) + 2 * q; }
-                float v = 0.f;
-                if (n0 + j < g.N && k0 + kk < kend) v = B[b_addr(j, k0 + kk)];
-                rb[q] = v;
-            }
+        for (int q = 0; q < NB; q++) {
+            const int kk = k0 + bk[q];
+            const bool ok = n0 + bj[q] < g.N && kk < kend;
+            if (VB) { gf4 v = {0.f, 0.f, 0.f, 0.f}; if (ok) v = *(const gf4 *)(B + boff[q] + koff_b(kk)); rb4[q] = v; }
+            else { float v = 0.f; if (ok) v = B[boff[q] + koff_b(kk)]; rb[q] = v; }
         }
     };
     auto store_tile = [&]() {
-        if (VA) {
 #pragma unroll
-            for (int q = 0; q < AV; q++) {
-                if (A_KC) {
-                    const int kk = (tid & 7) * 4, i = (tid >> 3) + 32 * q;
+        for (int q = 0; q < NA; q++) {
+            if (VA && A_KC) {
 #pragma unroll
-                    for (int e = 0; e < 4; e++) As[(kk + e) * LDA + i] = ra4[q][e];
-                } else {
-                    const int i = (tid & (BM / 4 - 1)) * 4, kk = tid / (BM / 4) + (1024 / BM) * q;
-                    *(gf4 *)(As + kk * LDA + i) = ra4[q];
-                }
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < AE; q++) {
-                int i, kk;
-                if (A_KC) { kk = tid & 31; i = (tid >> 5) + 8 * q; }
-                else { i = tid % BM; kk = tid / BM + (256 / BM) * q; }
-                As[kk * LDA + i] = ra[q];
-            }
+                for (int e = 0; e < 4; e++) As[(ak[q] + e) * LDA + ai[q]] = ra4[q][e];
+            } else if (VA) *(gf4 *)(As + ak[q] * LDA + ai[q]) = ra4[q];
+            else As[ak[q] * LDA + ai[q]] = ra[q];
         }
-        if (VB) {
 #pragma unroll
-            for (int q = 0; q < BV; q++) {
-                if (B_KC) {
-                    const int kk = (tid & 7) * 4, j = (tid >> 3) + 32 * q;
+        for (int q = 0; q < NB; q++) {
+            if (VB && B_KC) {
 #pragma unroll
-                    for (int e = 0; e < 4; e++) Bs[(kk + e) * LDB + j] = rb4[q][e];
-                } else {
-                    const int j = (tid & 31) * 4, kk = (tid >> 5) + 8 * q;
-                    *(gf4 *)(Bs + kk * LDB + j) = rb4[q];
-                }
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < BE; q++) {
-                int j, kk;
-                if (B_KC) { kk = tid & 31; j = (tid >> 5) + 8 * q; }
-                else { j = tid & 127; kk = (tid >> 7) + 2 * q; }
-                Bs[kk * LDB + j] = rb[q];
-            }
+                for (int e = 0; e < 4; e++) Bs[(bk[q] + e) * LDB + bj[q]] = rb4[q][e];
+            } else if (VB) *(gf4 *)(Bs + bk[q] * LDB + bj[q]) = rb4[q];
+            else Bs[bk[q] * LDB + bj[q]] = rb[q];
         }
     };
 
