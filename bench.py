@@ -85,6 +85,7 @@ def main():
     if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29571")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # single node: the container hostname may not resolve
         import torch.distributed as dist  # rendezvous + barrier + max-reduce only (gloo); collectives are RCCL in C
         dist.init_process_group("gloo", rank=rank, world_size=world)
 

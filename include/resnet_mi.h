@@ -241,7 +241,9 @@ int mi_batch_last_status(const Batch *b);
 void mi_trainer_set_full_store(Train_ResNet *t, int on); /* also keep x-hat / BN-out / pre-ReLU sums (dump parity) */
 void mi_trainer_set_dump_root(Train_ResNet *t, const char *root); /* replaces /mnt/storage/.../training_dumps */
 void mi_trainer_set_dump_every(Train_ResNet *t, int every);       /* reference: 1000 (:2947); 0 disables */
-void mi_trainer_set_input_reset(Train_ResNet *t, int on);         /* reference zeroes images/labels each update (:2981) */
+void mi_trainer_set_input_reset(Train_ResNet *t, int on);
+/* 1 (default): each layer's weight gradient runs on a second compute stream next to the following layer's BN backward */
+void mi_trainer_set_overlap(Train_ResNet *t, int on);         /* reference zeroes images/labels each update (:2981) */
 float mi_host_loss(Train_ResNet *t, int *n_wrong);                /* resnet.cu:3363-3383 on pred_cpu */
 
 /* raw device access for tests / weight injection (model_params/%03d.buffer semantics, resnet.cu:2845-2874) */

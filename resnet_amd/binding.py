@@ -131,6 +131,7 @@ PROTOTYPES = {
     "mi_trainer_set_dump_root": (None, [_T, _cp]),
     "mi_trainer_set_dump_every": (None, [_T, _i]),
     "mi_trainer_set_input_reset": (None, [_T, _i]),
+    "mi_trainer_set_overlap": (None, [_T, _i]),
     "mi_host_loss": (_f, [_T, _ip]),
     "mi_copy_to_device": (None, [_vp, _vp, _sz]),
     "mi_copy_to_host": (None, [_vp, _vp, _sz]),

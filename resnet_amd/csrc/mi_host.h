@@ -16,7 +16,7 @@ void mi_synth_labels(int *out, size_t n, uint64_t seed, uint64_t offset, int n_c
  * one communication stream (RCCL), one copy stream (H2D of the next batch) */
 typedef struct {
     int ready;
-    mid_stream compute, comm, copy;
+    mid_stream compute, comm, copy, aux; /* aux: weight-gradient kernels, concurrent with the next layer's BN' */
 } MiGlobal;
 MiGlobal *mi_global(void);
 
@@ -61,6 +61,9 @@ typedef struct MiCtx {
     size_t dp_cursor; /* floats: gradients [dp_cursor, arena_floats) already handed to RCCL */
     mid_event ev_grads, ev_reduced;
     int dp_pending;
+    /* weight-gradient overlap: wgrad(L) runs on the aux stream next to BN'(L-1); joined before the next dgrad */
+    int overlap_wgrad, wgrad_pending;
+    mid_event ev_bn_done, ev_wgrad_done;
     /* timing */
     mid_event ev_t[6];
     float last_ms[5];

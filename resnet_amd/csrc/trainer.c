@@ -27,6 +27,7 @@ MiGlobal *mi_global(void) {
         G.compute = mid_stream_create();
         G.comm = mid_stream_create();
         G.copy = mid_stream_create();
+        G.aux = mid_stream_create();
         G.ready = 1;
     }
     return &G;
@@ -316,6 +317,8 @@ Train_ResNet *init_trainer(ResNet *model, Batch *cur_batch, int batch_size, floa
     c->dump_every = 1000; /* resnet.cu:2947 */
     c->input_reset = 1;   /* resnet.cu:2981-2982 */
     c->world = 1; c->bucket_bytes = (size_t)32 << 20;
+    c->overlap_wgrad = 1;
+    c->ev_bn_done = mid_event_create(); c->ev_wgrad_done = mid_event_create();
 
     Forward_Buffer *fb = (Forward_Buffer *)calloc(1, sizeof(Forward_Buffer));
     fb->activations = build_activations(c, d, blocks, batch_size, NULL);
@@ -381,6 +384,7 @@ void mi_trainer_set_full_store(Train_ResNet *t, int on) {
 #undef EXTRA
 }
 void mi_trainer_set_dump_every(Train_ResNet *t, int every) { ctx_of(t)->dump_every = every; }
+void mi_trainer_set_overlap(Train_ResNet *t, int on) { ctx_of(t)->overlap_wgrad = on; }
 void mi_trainer_set_input_reset(Train_ResNet *t, int on) { ctx_of(t)->input_reset = on; }
 void mi_trainer_set_dump_root(Train_ResNet *t, const char *root) {
     MiCtx *c = ctx_of(t);
@@ -477,15 +481,29 @@ float mi_host_loss(Train_ResNet *t, int *n_wrong) {
 }
 
 /* BN' (+fused ReLU') then conv' : prepareAndDoActivationAndBatchNormDeriv + prepreAndDoConvolutionDeriv */
+/* the aux stream must have finished the previous weight gradient before a dgrad may overwrite the rolling buffer it reads */
+static void join_wgrad(MiCtx *c) {
+    if (c->wgrad_pending) { mid_stream_wait_event(G.compute, c->ev_wgrad_done); c->wgrad_pending = 0; }
+}
 static void unit_bwd(Train_ResNet *t, const float *in, const float *w, const BatchNorm *bn, const Cache_BatchNorm *cache,
                      const BatchNorm *dbn, const float *conv_out, const float *dy, const float *mask_src, int mask_mode,
                      float *d_conv_out, float *dx, const float *addend, float *dw, int C, int H, int K, int k, int stride) {
     MiCtx *c = ctx_of(t);
     const int N = t->batch_size, Ho = H / stride;
+    /* BN' of this unit (HBM-bound) runs next to the previous unit's weight gradient (FMA-bound, aux stream) */
     mid_bn_bwd(G.compute, c->bn_ws, conv_out, bn->gamma, bn->beta, cache->means, cache->vars, dy, mask_src, d_conv_out,
                dbn->gamma, dbn->beta, N, K, Ho * Ho, t->eps, mask_mode);
+    join_wgrad(c);
     if (dx) mid_conv_dgrad(G.compute, &c->ws, w, d_conv_out, dx, addend, N, C, H, K, k, stride);
-    mid_conv_wgrad(G.compute, &c->ws, in, d_conv_out, dw, N, C, H, K, k, stride);
+    if (c->overlap_wgrad) {
+        /* d_conv_out is complete once BN' is: order the aux stream after this point of the compute stream.  The event is
+         * recorded after the dgrad launch only because both read d_conv_out; the dgrad itself does not gate the wgrad. */
+        mid_event_record(c->ev_bn_done, G.compute);
+        mid_stream_wait_event(G.aux, c->ev_bn_done);
+        mid_conv_wgrad(G.aux, &c->ws, in, d_conv_out, dw, N, C, H, K, k, stride);
+        mid_event_record(c->ev_wgrad_done, G.aux);
+        c->wgrad_pending = 1;
+    } else mid_conv_wgrad(G.compute, &c->ws, in, d_conv_out, dw, N, C, H, K, k, stride);
 }
 
 /* resnet.cu:1777-2248 */
@@ -559,7 +577,9 @@ void backwards_pass(Train_ResNet *t) {
  * (the order update_parameters walks, resnet.cu:2952). */
 void mi_dp_reduce_ready(Train_ResNet *t, size_t from, int force) {
     MiCtx *c = ctx_of(t);
+    if (force) join_wgrad(c); /* end of backward: every weight gradient is on the compute stream's timeline */
     if (!c->comm) return;
+    join_wgrad(c);
     if (from >= c->dp_cursor) return;
     const size_t n = c->dp_cursor - from;
     if (!force && n * sizeof(float) < c->bucket_bytes) return;
@@ -628,6 +648,7 @@ void destroy_trainer(Train_ResNet *t) {
     mid_free_host(t->forward_buffer->pred_cpu);
     mid_free_host(c->nan_flag_host);
     mid_event_destroy(c->ev_grads); mid_event_destroy(c->ev_reduced);
+    mid_event_destroy(c->ev_bn_done); mid_event_destroy(c->ev_wgrad_done);
     for (int i = 0; i < 6; i++) mid_event_destroy(c->ev_t[i]);
     free_activations_host(t->forward_buffer->activations);
     free_activations_host(t->backprop_buffer->activation_derivs);
