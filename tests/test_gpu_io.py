@@ -128,3 +128,23 @@ def test_dump_and_resume(tmp_path):
     assert np.allclose(got, ref_losses, rtol=1e-5), (got, ref_losses)
     assert np.allclose(b.get("params", 3), ref_param, rtol=1e-4, atol=1e-6)
     b.close()
+
+
+def test_reference_style_c_driver(tmp_path):
+    """examples/resnet_main.c -- the reference's main() rebuilt on the C-ABI: plain C, gcc, linked against the library;
+    prints the reference's per-iteration line (resnet.cu:3386) and writes avg_loss_log.txt (resnet.cu:3388)"""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "ResNetMI")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "resnet_main.c"),
+                           "-L", os.path.join(root, "resnet_amd"), "-lresnet_mi", "-lm",
+                           "-Wl,-rpath," + os.path.join(root, "resnet_amd"), "-o", exe])
+    log = str(tmp_path / "avg_loss_log.txt")
+    out = subprocess.check_output([exe, "--input", "32", "--blocks", "1", "--batch", "8", "--iters", "6", "--loss-log", log],
+                                  timeout=300).decode()
+    lines = re.findall(r"Epoch: 0, Batch: (\d+) ----- Avg\. Loss: ([0-9.]+), Accuracy: ([0-9.]+)%", out)
+    assert [int(a) for a, _, _ in lines] == list(range(6))
+    losses = [float(x) for x in open(log).read().split()]
+    assert len(losses) == 6 and all(np.isfinite(losses)) and [float(b) for _, b, _ in lines] == losses
+    assert 6.0 < losses[0] < 8.0  # ln(1000) = 6.9 at random init
