@@ -176,3 +176,39 @@ def test_data_parallel_path_single_rank(oracle):
     finally:
         tr.close()
         net.close()
+
+
+def test_reference_resnet50_step_parity(oracle, oracle64):
+    """the benchmark architecture itself (16 bottleneck blocks, 160 tensors, 47.58 M parameters, every layer shape incl. the
+    three 3x3-s2 projections) at batch 2.  53 BN layers over as few as 98 samples per channel amplify rounding, so the
+    yardstick is the oracle's own fp32 error: the HIP path must be as close to the double-accumulation oracle as the
+    sequential-fp32 oracle is (factor 3), for the last activation, the loss and every gradient tensor."""
+    from oracle.oracle_py import OracleNet
+    dims, batch = synth.R50_DIMS, 2
+    net, tr = _make(dims, batch, oracle)
+    ref = OracleNet(oracle64, dims, batch)
+    try:
+        assert net.n_locations == 160 and sum(net.sizes) == 47576128  # BASELINE.md section 2
+        for i in range(net.n_locations):
+            ref.param(i)[:] = net.param(i)
+        im, lab = synth.make_batch(dims, batch, step=0)
+        ref.set_batch(im, lab)
+        _step(net, tr, dims, batch, 0)
+        ref.forward()
+        name = "conv_blocks/15/output_activated"
+        e_gpu, e_f32 = rel_l2(nhwc(tr.activation(name)), ref.tensor(name)), rel_l2(net.tensor(name), ref.tensor(name))
+        assert e_gpu <= 3 * e_f32 + 1e-6, (e_gpu, e_f32)
+        (gl, gw), (ol, ow), (rl, rw) = tr.loss(), net.loss(), ref.loss()
+        assert abs(gl - rl) <= 3 * abs(ol - rl) + LOSS_ABS * max(1.0, abs(rl)), (gl, ol, rl)
+        net.backward(); tr.backward(); tr.check(); ref.backward()
+        worst_gpu = worst_f32 = 0.0
+        for i in range(net.n_locations):
+            g_gpu, g_f32 = rel_l2(tr.get("grads", i), ref.grad(i)), rel_l2(net.grad(i), ref.grad(i))
+            worst_gpu, worst_f32 = max(worst_gpu, g_gpu), max(worst_f32, g_f32)
+            assert g_gpu <= 3 * g_f32 + GRAD_REL_L2, "gradient of location %d: HIP %.3e, fp32 oracle %.3e vs f64 oracle" % (i, g_gpu, g_f32)
+        print("ResNet-50 batch 2 vs f64 oracle: activation err HIP %.2e / fp32-oracle %.2e; loss %.6f / %.6f / %.6f; "
+              "worst gradient err HIP %.2e / fp32-oracle %.2e" % (e_gpu, e_f32, gl, ol, rl, worst_gpu, worst_f32))
+    finally:
+        tr.close()
+        net.close()
+        ref.close()
