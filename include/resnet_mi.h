@@ -242,8 +242,11 @@ void mi_trainer_set_full_store(Train_ResNet *t, int on); /* also keep x-hat / BN
 void mi_trainer_set_dump_root(Train_ResNet *t, const char *root); /* replaces /mnt/storage/.../training_dumps */
 void mi_trainer_set_dump_every(Train_ResNet *t, int every);       /* reference: 1000 (:2947); 0 disables */
 void mi_trainer_set_input_reset(Train_ResNet *t, int on);
-/* 1 (default): each layer's weight gradient runs on a second compute stream next to the following layer's BN backward */
-void mi_trainer_set_overlap(Train_ResNet *t, int on);         /* reference zeroes images/labels each update (:2981) */
+/* weight-gradient scheduling in backwards_pass.  0: everything on one stream, in the reference's order.  1: each layer's
+ * weight gradient runs on a second stream next to the following layer's BN backward only (default).  2: weight gradients
+ * run free on a low-priority second stream; the derivative tensors they read come from a ring of buffers and are only
+ * rewritten after the reader has finished.  Results are bit-identical in all three modes. */
+void mi_trainer_set_overlap(Train_ResNet *t, int mode);
 float mi_host_loss(Train_ResNet *t, int *n_wrong);                /* resnet.cu:3363-3383 on pred_cpu */
 
 /* raw device access for tests / weight injection (model_params/%03d.buffer semantics, resnet.cu:2845-2874) */

@@ -30,6 +30,7 @@ void mid_memcpy_d2h(void *dst, const void *src, size_t bytes, mid_stream s);
 void mid_memcpy_d2d(void *dst, const void *src, size_t bytes, mid_stream s);
 void mid_memset(void *dst, int byte, size_t bytes, mid_stream s);
 mid_stream mid_stream_create(void);
+mid_stream mid_stream_create_low_priority(void);
 void mid_stream_destroy(mid_stream s);
 void mid_stream_sync(mid_stream s);
 void mid_device_sync(void);

@@ -62,8 +62,15 @@ typedef struct MiCtx {
     mid_event ev_grads, ev_reduced;
     int dp_pending;
     /* weight-gradient overlap: wgrad(L) runs on the aux stream next to BN'(L-1); joined before the next dgrad */
-    int overlap_wgrad, wgrad_pending;
+    int overlap_wgrad, wgrad_pending; /* 0 serial, 1 wgrad next to the following BN' only, 2 free-running (ring of buffers) */
     mid_event ev_bn_done, ev_wgrad_done;
+    /* mode 2: derivative tensors of the backward chain come from a ring; a slot remembers the aux-stream weight gradient
+     * that still reads it, and the compute stream waits for exactly that kernel before the slot is written again */
+#define MI_RING 10
+    float *ring_buf[MI_RING];
+    mid_event ring_ev[MI_RING];
+    int ring_busy[MI_RING], ring_next;
+    float *dpool[6]; /* the fixed U0,U1,A,B,C,D buffers of modes 0/1 */
     /* timing */
     mid_event ev_t[6];
     float last_ms[5];

@@ -54,6 +54,14 @@ mid_stream mid_stream_create(void) {
     HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     return (mid_stream)s;
 }
+/* a stream whose workgroups are dispatched only when the normal-priority streams leave capacity */
+mid_stream mid_stream_create_low_priority(void) {
+    int lo = 0, hi = 0;
+    hipStream_t s = nullptr;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; }
+    HIPCHK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, lo)); /* numerically greatest = lowest priority */
+    return (mid_stream)s;
+}
 void mid_stream_destroy(mid_stream s) { if (s) HIPCHK(hipStreamDestroy((hipStream_t)s)); }
 void mid_stream_sync(mid_stream s) { HIPCHK(hipStreamSynchronize((hipStream_t)s)); }
 void mid_device_sync(void) { HIPCHK(hipDeviceSynchronize()); }

@@ -27,7 +27,7 @@ MiGlobal *mi_global(void) {
         G.compute = mid_stream_create();
         G.comm = mid_stream_create();
         G.copy = mid_stream_create();
-        G.aux = mid_stream_create();
+        G.aux = mid_stream_create_low_priority();
         G.ready = 1;
     }
     return &G;
@@ -317,7 +317,7 @@ Train_ResNet *init_trainer(ResNet *model, Batch *cur_batch, int batch_size, floa
     c->dump_every = 1000; /* resnet.cu:2947 */
     c->input_reset = 1;   /* resnet.cu:2981-2982 */
     c->world = 1; c->bucket_bytes = (size_t)32 << 20;
-    c->overlap_wgrad = 1;
+    c->overlap_wgrad = getenv("RESNET_MI_OVERLAP") ? atoi(getenv("RESNET_MI_OVERLAP")) : 1;
     c->ev_bn_done = mid_event_create(); c->ev_wgrad_done = mid_event_create();
 
     Forward_Buffer *fb = (Forward_Buffer *)calloc(1, sizeof(Forward_Buffer));
@@ -338,6 +338,8 @@ Train_ResNet *init_trainer(ResNet *model, Batch *cur_batch, int batch_size, floa
     const size_t maxe = max_tensor_elems(d, blocks, batch_size);
     float *pool[6];
     for (int i = 0; i < 6; i++) pool[i] = falloc(c, maxe);
+    for (int i = 0; i < 6; i++) c->dpool[i] = pool[i];
+    for (int i = 0; i < MI_RING; i++) { c->ring_buf[i] = i < 4 ? pool[2 + i] : falloc(c, maxe); c->ring_ev[i] = mid_event_create(); }
     bb->activation_derivs = build_activations(c, d, blocks, batch_size, pool);
     t->backprop_buffer = bb;
     size_workspaces(c, d, blocks, batch_size);
@@ -384,7 +386,25 @@ void mi_trainer_set_full_store(Train_ResNet *t, int on) {
 #undef EXTRA
 }
 void mi_trainer_set_dump_every(Train_ResNet *t, int every) { ctx_of(t)->dump_every = every; }
-void mi_trainer_set_overlap(Train_ResNet *t, int on) { ctx_of(t)->overlap_wgrad = on; }
+void mi_trainer_set_overlap(Train_ResNet *t, int mode) {
+    MiCtx *c = ctx_of(t);
+    mid_stream_sync(G.aux); mid_stream_sync(G.compute);
+    c->overlap_wgrad = mode < 0 ? 0 : mode > 2 ? 2 : mode;
+    c->wgrad_pending = 0;
+    for (int i = 0; i < MI_RING; i++) c->ring_busy[i] = 0;
+    if (c->overlap_wgrad != 2) { /* back to the fixed aliasing of build_activations */
+        Activations *da = t->backprop_buffer->activation_derivs;
+        float **pool = c->dpool;
+        da->init_conv_applied = pool[3]; da->init_conv_activated = pool[2];
+        for (int i = 0; i < da->n_conv_blocks; i++) {
+            Activation_ConvBlock *k = da->activation_conv_blocks[i];
+            k->output = pool[5];
+            if (k->transformed_residual) k->transformed_residual = pool[2];
+            k->post_expanded = pool[3]; k->post_spatial_activated = pool[4]; k->post_spatial = pool[2];
+            k->post_reduced_activated = pool[3]; k->post_reduced = pool[4];
+        }
+    }
+}
 void mi_trainer_set_input_reset(Train_ResNet *t, int on) { ctx_of(t)->input_reset = on; }
 void mi_trainer_set_dump_root(Train_ResNet *t, const char *root) {
     MiCtx *c = ctx_of(t);
@@ -485,19 +505,40 @@ float mi_host_loss(Train_ResNet *t, int *n_wrong) {
 static void join_wgrad(MiCtx *c) {
     if (c->wgrad_pending) { mid_stream_wait_event(G.compute, c->ev_wgrad_done); c->wgrad_pending = 0; }
 }
+/* mode 2: next slot of the derivative ring; the compute stream first waits for the weight gradient (if any) that still
+ * reads the slot's previous contents */
+static float *ring_take(MiCtx *c, int *slot) {
+    const int i = c->ring_next;
+    c->ring_next = (i + 1) % MI_RING;
+    if (c->ring_busy[i]) { mid_stream_wait_event(G.compute, c->ring_ev[i]); c->ring_busy[i] = 0; }
+    if (slot) *slot = i;
+    return c->ring_buf[i];
+}
+/* d_slot: ring slot holding d_conv_out (mode 2), -1 otherwise */
 static void unit_bwd(Train_ResNet *t, const float *in, const float *w, const BatchNorm *bn, const Cache_BatchNorm *cache,
                      const BatchNorm *dbn, const float *conv_out, const float *dy, const float *mask_src, int mask_mode,
-                     float *d_conv_out, float *dx, const float *addend, float *dw, int C, int H, int K, int k, int stride) {
+                     float *d_conv_out, int d_slot, float *dx, const float *addend, float *dw, int C, int H, int K, int k,
+                     int stride) {
     MiCtx *c = ctx_of(t);
     const int N = t->batch_size, Ho = H / stride;
-    /* BN' of this unit (HBM-bound) runs next to the previous unit's weight gradient (FMA-bound, aux stream) */
+    /* BN' of this unit (HBM-bound) runs next to earlier units' weight gradients (FMA-bound, low-priority aux stream) */
     mid_bn_bwd(G.compute, c->bn_ws, conv_out, bn->gamma, bn->beta, cache->means, cache->vars, dy, mask_src, d_conv_out,
                dbn->gamma, dbn->beta, N, K, Ho * Ho, t->eps, mask_mode);
+    if (c->overlap_wgrad == 2 && d_slot >= 0) {
+        /* d_conv_out is final once BN' is: the weight gradient may start now and run for as long as the slot lives */
+        mid_event_record(c->ev_bn_done, G.compute);
+        mid_stream_wait_event(G.aux, c->ev_bn_done);
+        mid_conv_wgrad(G.aux, &c->ws, in, d_conv_out, dw, N, C, H, K, k, stride);
+        mid_event_record(c->ring_ev[d_slot], G.aux);
+        c->ring_busy[d_slot] = 1;
+        mid_event_record(c->ev_wgrad_done, G.aux);
+        c->wgrad_pending = 1;
+        if (dx) mid_conv_dgrad(G.compute, &c->ws, w, d_conv_out, dx, addend, N, C, H, K, k, stride);
+        return;
+    }
     join_wgrad(c);
     if (dx) mid_conv_dgrad(G.compute, &c->ws, w, d_conv_out, dx, addend, N, C, H, K, k, stride);
     if (c->overlap_wgrad) {
-        /* d_conv_out is complete once BN' is: order the aux stream after this point of the compute stream.  The event is
-         * recorded after the dgrad launch only because both read d_conv_out; the dgrad itself does not gate the wgrad. */
         mid_event_record(c->ev_bn_done, G.compute);
         mid_stream_wait_event(G.aux, c->ev_bn_done);
         mid_conv_wgrad(G.aux, &c->ws, in, d_conv_out, dw, N, C, H, K, k, stride);
@@ -527,21 +568,25 @@ void backwards_pass(Train_ResNet *t) {
     const ConvBlock *last = p->conv_blocks[nb - 1];
     const int Hl = last->incoming_spatial_dim;
     mid_avgpool_bwd(G.compute, da->final_conv_output_pooled, da->activation_conv_blocks[nb - 1]->output_activated, N, D, Hl * Hl);
+    const int ring = c->overlap_wgrad == 2;
     for (int i = nb - 1; i >= 0; i--) {
         const ConvBlock *b = p->conv_blocks[i];
         const ConvBlock *db = dp->conv_blocks[i];
         const Activation_ConvBlock *k = a->activation_conv_blocks[i];
-        const Activation_ConvBlock *dk = da->activation_conv_blocks[i];
+        Activation_ConvBlock *dk = da->activation_conv_blocks[i];
         const float *bin = i == 0 ? a->init_convblock_input : a->activation_conv_blocks[i - 1]->output_activated;
         float *dbin = i == 0 ? da->init_convblock_input : da->activation_conv_blocks[i - 1]->output_activated;
         const int H = b->incoming_spatial_dim, Ho = H / b->stride;
         const float *up = dk->output_activated; /* dL/d(block output) */
         const float *exp_dy, *exp_mask, *red_addend;
-        int exp_mode;
+        int exp_mode, s_proj = -1, s_exp = -1, s_spa = -1, s_red = -1;
+        if (ring) { /* this block's derivative tensors: fresh ring slots (resnet_cudnn_lowmem.cu:2152-2170 keeps four) */
+            if (b->projection) dk->transformed_residual = ring_take(c, &s_proj); else dk->output = ring_take(c, NULL);
+        }
         if (b->projection) {
             /* ReLU' of the block output is fused into both BN' as an external mask (doActivationDeriv, :1934) */
             unit_bwd(t, bin, b->projection, b->norm_projection, k->norm_post_projection, db->norm_projection,
-                     k->transformed_residual, up, k->output_activated, 2, dk->transformed_residual, dbin, NULL,
+                     k->transformed_residual, up, k->output_activated, 2, dk->transformed_residual, s_proj, dbin, NULL,
                      db->projection, b->incoming_filters, H, b->expanded_depth, b->stride == 2 ? 3 : 1, b->stride);
             exp_dy = up; exp_mask = k->output_activated; exp_mode = 2;
             red_addend = dbin; /* reduce-conv dgrad accumulates onto the projection path (toAdd, :2157) */
@@ -550,23 +595,28 @@ void backwards_pass(Train_ResNet *t) {
             exp_dy = dk->output; exp_mask = NULL; exp_mode = 0;
             red_addend = dk->output; /* identity shortcut: setVal 0 + addVec (:2003-2004) folded into the dgrad epilogue */
         }
+        if (ring) { dk->post_expanded = ring_take(c, &s_exp); dk->post_spatial_activated = ring_take(c, NULL); }
         unit_bwd(t, k->post_spatial_activated, b->depth_expansion, b->norm_expansion, k->norm_post_expanded,
-                 db->norm_expansion, k->post_expanded, exp_dy, exp_mask, exp_mode, dk->post_expanded,
+                 db->norm_expansion, k->post_expanded, exp_dy, exp_mask, exp_mode, dk->post_expanded, s_exp,
                  dk->post_spatial_activated, NULL, db->depth_expansion, b->reduced_depth, Ho, b->expanded_depth, 1, 1);
         /* the call resnet.cu:2060-2083 forgot; present in resnet_cudnn.cu:2365-2366 */
+        if (ring) { dk->post_spatial = ring_take(c, &s_spa); dk->post_reduced_activated = ring_take(c, NULL); }
         unit_bwd(t, k->post_reduced_activated, b->spatial, b->norm_spatial, k->norm_post_spatial, db->norm_spatial,
-                 k->post_spatial, dk->post_spatial_activated, NULL, 1, dk->post_spatial, dk->post_reduced_activated, NULL,
+                 k->post_spatial, dk->post_spatial_activated, NULL, 1, dk->post_spatial, s_spa, dk->post_reduced_activated, NULL,
                  db->spatial, b->reduced_depth, H, b->reduced_depth, 3, b->stride);
+        if (ring) dk->post_reduced = ring_take(c, &s_red);
         unit_bwd(t, bin, b->depth_reduction, b->norm_depth_reduction, k->norm_post_reduced, db->norm_depth_reduction,
-                 k->post_reduced, dk->post_reduced_activated, NULL, 1, dk->post_reduced, dbin, red_addend,
+                 k->post_reduced, dk->post_reduced_activated, NULL, 1, dk->post_reduced, s_red, dbin, red_addend,
                  db->depth_reduction, b->incoming_filters, H, b->reduced_depth, 1, 1);
         mi_dp_reduce_ready(t, (size_t)(db->depth_reduction - c->g_arena), 0);
     }
     const int Hs = d->input / d->init_conv_stride;
+    int s_stem = -1;
+    if (ring) { da->init_conv_activated = ring_take(c, NULL); da->init_conv_applied = ring_take(c, &s_stem); }
     mid_maxpool_bwd(G.compute, a->max_inds, da->init_convblock_input, da->init_conv_activated, N, d->init_conv_filters, Hs,
                     d->init_maxpool_dim, d->init_maxpool_stride);
     unit_bwd(t, t->cur_batch->images, p->init_conv_layer, p->norm_init_conv, a->norm_init_conv, dp->norm_init_conv,
-             a->init_conv_applied, da->init_conv_activated, NULL, 1, da->init_conv_applied, NULL, NULL,
+             a->init_conv_applied, da->init_conv_activated, NULL, 1, da->init_conv_applied, s_stem, NULL, NULL,
              dp->init_conv_layer, 3, d->input, d->init_conv_filters, d->init_kernel_dim, d->init_conv_stride);
     mi_dp_reduce_ready(t, 0, 1);
     mid_event_record(c->ev_t[3], G.compute);
@@ -577,14 +627,17 @@ void backwards_pass(Train_ResNet *t) {
  * (the order update_parameters walks, resnet.cu:2952). */
 void mi_dp_reduce_ready(Train_ResNet *t, size_t from, int force) {
     MiCtx *c = ctx_of(t);
+    const int pending = c->wgrad_pending;
     if (force) join_wgrad(c); /* end of backward: every weight gradient is on the compute stream's timeline */
     if (!c->comm) return;
-    join_wgrad(c);
     if (from >= c->dp_cursor) return;
     const size_t n = c->dp_cursor - from;
     if (!force && n * sizeof(float) < c->bucket_bytes) return;
     mid_event_record(c->ev_grads, G.compute);
     mid_stream_wait_event(G.comm, c->ev_grads);
+    /* the bucket also holds weight gradients from the aux stream: the comm stream waits for the latest of them itself,
+     * the compute stream does not stall */
+    if (pending) mid_stream_wait_event(G.comm, c->ev_wgrad_done);
     mid_rccl_allreduce_sum(c->comm, c->g_arena + from, n, G.comm);
     c->dp_cursor = from;
     c->dp_pending = 1;
@@ -649,6 +702,7 @@ void destroy_trainer(Train_ResNet *t) {
     mid_free_host(c->nan_flag_host);
     mid_event_destroy(c->ev_grads); mid_event_destroy(c->ev_reduced);
     mid_event_destroy(c->ev_bn_done); mid_event_destroy(c->ev_wgrad_done);
+    for (int i = 0; i < MI_RING; i++) mid_event_destroy(c->ring_ev[i]);
     for (int i = 0; i < 6; i++) mid_event_destroy(c->ev_t[i]);
     free_activations_host(t->forward_buffer->activations);
     free_activations_host(t->backprop_buffer->activation_derivs);

@@ -143,6 +143,38 @@ def test_synthetic_source_and_reproducibility():
     assert all(np.isfinite(losses[0]))
 
 
+@pytest.mark.parametrize("cfg", ["C1S", "R50x8"])
+def test_wgrad_scheduling_modes_bit_identical(cfg):
+    """mi_trainer_set_overlap: serial (0), wgrad next to the following BN' (1) and free-running wgrads over the ring of
+    derivative buffers (2) are schedules of the same kernels on the same data -- gradients, parameters and losses after
+    three steps must be bit-identical.  A missing ring wait (a derivative buffer rewritten under a running weight
+    gradient) shows up here as a difference."""
+    from resnet_amd import Trainer
+    dims, batch = (synth.C1S_DIMS, 4) if cfg == "C1S" else (synth.R50_DIMS, 8)
+    outs = []
+    for mode in (0, 1, 2, 21):
+        tr = Trainer(dims, batch, seed=1236)
+        tr.source_synthetic(1234, 1235, pool_batches=2)
+        tr.L.mi_trainer_set_overlap(tr.t, min(mode, 2))
+        losses = []
+        tr.load_new_batch(); tr.forward(); losses.append(tr.loss()[0]); tr.backward()
+        g0 = [tr.get("grads", i).copy() for i in range(len(tr.sizes))]
+        tr.update()
+        if mode == 21:  # switch 2 -> 1 between steps: the fixed buffer aliasing is restored
+            tr.L.mi_trainer_set_overlap(tr.t, 1)
+        for _ in range(2):
+            losses.append(tr.step()[0])
+        tr.check()
+        outs.append((losses, [tr.get("params", i).copy() for i in range(len(tr.sizes))],
+                     [tr.get("means", i).copy() for i in range(len(tr.sizes))], g0))
+        tr.close()
+    for o in outs[1:]:
+        assert o[0] == outs[0][0]
+        for k in (1, 2, 3):
+            for a, b in zip(o[k], outs[0][k]):
+                assert np.array_equal(a, b)
+
+
 def test_weight_init_matches_stream():
     from resnet_amd import Trainer
     dims = synth.C1_DIMS
