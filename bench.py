@@ -23,7 +23,8 @@ sys.path.insert(0, ROOT)
 FP32_PEAK_TFLOPS = 157.3  # gfx950 fp32: vector FMA rate == fp32 MFMA rate (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 FAMILIES = {0: "direct conv 3x3/7x7 fwd+dgrad (dconv_kernel, VALU)", 1: "direct conv wgrad (wgrad_kernel, VALU)",
-            2: "1x1 conv / FC GEMM (gemm_mfma_kernel, fp32 MFMA)", 3: "batch norm fwd+bwd"}
+            2: "1x1 conv / FC GEMM (gemm_mfma_kernel, fp32 MFMA)", 3: "batch norm fwd+bwd",
+            5: "3x3-s2 projection conv fwd+dgrad+wgrad (pconv_mfma_kernel, implicit GEMM on fp32 MFMA)"}
 
 
 def cpu_baseline(seconds_budget=30.0):
@@ -175,7 +176,7 @@ def main():
             # HBM traffic of that family from the committed rocprofv3 PMC passes (bench.py cannot run the profiler itself)
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-                key = {0: "dconv", 1: "wgradC", 2: "gemm", 3: "bn"}[dom]
+                key = {0: "dconv", 1: "wgradC", 2: "gemm", 3: "bn", 5: "pconv"}[dom]
                 # the PMC passes count kernel launches, this run counts logical launches (the four concurrent stride-2 dgrad
                 # class kernels are one): convert through bytes per step
                 roof["traffic"] = round(pmc["families"][key]["hbm_GB_per_step_raw"] * 1e9 / (n / args.steps))

@@ -1,0 +1,414 @@
+// kernels_pconv.hip -- the reference's PROJECTION shortcuts on the CDNA4 matrix cores.
+//
+// The reference's striding blocks project the residual with a 3x3 / stride-2 / pad-1 convolution
+// (resnet.cu:884-889, 1693-1700), not the usual 1x1: 256->512 @56, 512->1024 @28, 1024->2048 @14.  Those three layers
+// hold 57% of the network's multiply-adds, and with C, K >= 256 they are GEMM-shaped: per output tile the reduction
+// runs over 9*C >= 2304 terms.  They are computed here as an im2col-free implicit GEMM on fp32 MFMA
+// (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate): the "im2col" matrix exists only as the 32 x 128 tile
+// of LDS that the current k-step multiplies, gathered straight from the NCHW tensor.
+//
+//   forward  Y[n][k][ho][wo]  = sum_{t=(r,s)} sum_c W[k][c][r][s] X[n][c][2ho-1+r][2wo-1+s]
+//            M = K (out channels), N = (n,ho,wo), reduction (t,c) tap-major; A = weights re-laid [t][c][k]
+//   dgrad    dX[n][c][2a+ph][2b+pw] = sum over the 1/2/2/4 taps that reach parity class (ph,pw)
+//            M = C, N = (n,a,b), reduction (tap,k); A = weights re-laid [t][k][c]; the four classes are blockIdx.y
+//   wgrad    dW[k][c][t] = sum_{n,ho,wo} dY[n][k][ho][wo] X[n][c][2ho-1+r][2wo-1+s]
+//            M = K, N = (t,c), reduction (n,ho,wo) split over blockIdx.y; partials [split][t][k][c], reduced (and
+//            transposed to KCRS) by pconv_wgrad_reduce_kernel in a fixed order (deterministic)
+//
+// Tile 128 x 128 x 32, 256 threads = 4 waves of 64x64 (2x2 MFMA tiles).  LDS double-buffered: global loads of tile i+1
+// are issued before tile i is multiplied and stored after it, one barrier per k-step.  Out-of-image taps load from the
+// (always valid) centre tap's address and are zeroed when stored to LDS, so no load is predicated.
+// Block ids are re-mapped so that each XCD (ids round-robin over 8 XCDs) walks a contiguous range of tiles, M-tiles
+// fastest: the blocks that share a gathered pixel tile share an L2.
+#include "mi_common.hpp"
+#include "mi_device.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float pf4 __attribute__((ext_vector_type(4)));
+
+enum { PC_FWD = 0, PC_DGRAD = 1, PC_WGRAD = 2 };
+
+struct PcArgs {
+    int N, C, K, H, W, Ho, Wo; // 3x3, stride 2, pad 1: Ho = H/2, Wo = W/2 (H, W even)
+    int HW, P;                 // H*W, Ho*Wo
+    int ncols;                 // fwd/dgrad: N*P columns
+    int mtiles;                // number of 128-row tiles
+    int tiles;                 // mtiles * column tiles: blocks per blockIdx.y
+    int ctiles;                // wgrad: C/128
+    int klen;                  // wgrad: reduction length per split (multiple of 32)
+    FastDiv fdP, fdWo, fdM;    // fdM: division by mtiles
+};
+
+#define PC_BK 32
+
+template <int MODE>
+__global__ void __launch_bounds__(256)
+pconv_mfma_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float *__restrict__ Out,
+                  const float *__restrict__ addend, const PcArgs g) {
+    constexpr int LDA = (MODE == PC_WGRAD) ? 129 : 132; // 129: conflict-free transposed scalar stores; 132: 16-B rows
+    constexpr int LDB = (MODE == PC_WGRAD) ? 129 : 132;
+    extern __shared__ __attribute__((aligned(16))) float pc_smem[];
+    float *As = pc_smem;                   // [2][32][LDA]
+    float *Bs = pc_smem + 2 * PC_BK * LDA; // [2][32][LDB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- block -> tile (XCD-contiguous, M-tiles fastest) ----
+    uint32_t L = blockIdx.x;
+    {
+        const uint32_t per = (uint32_t)g.tiles >> 3;
+        if (L < per * 8) L = (L & 7) * per + (L >> 3);
+    }
+    const uint32_t ct = fd_div(L, g.fdM);
+    const int m0 = (int)(L - ct * g.mtiles) * 128;
+    const int n0 = (int)ct * 128;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    // ---- per-thread staging state ----
+    // FWD / DGRAD: A = 4 x float4 along M (rows a_k + 8q), B = 16 gathered scalars of ONE column (rows b_k + 2q)
+    // WGRAD:       A, B = 16 scalars each of ONE reduction index (tid & 31), rows/cols (tid >> 5) + 8q
+    const float *ap = nullptr;
+    const float *bp = nullptr;
+    uint32_t mask = 0; // FWD: bit t = tap t in the image; DGRAD: bit tt = class tap tt in the image
+    int ph = 0, pw = 0, ntw = 1, ntaps = 1;
+    int wg_t = 0, wg_r = 0, wg_s = 0, cblk = 0, kend = 0;
+    int ntiles = 0;
+    if (MODE == PC_FWD || MODE == PC_DGRAD) {
+        const int a_i = (tid & 31) * 4, a_k = tid >> 5;
+        const int Mdim = MODE == PC_FWD ? g.K : g.C;
+        ap = Aop + (size_t)a_k * Mdim + m0 + a_i;
+        const int j = n0 + (tid & 127);
+        const bool jin = j < g.ncols;
+        const uint32_t jc = jin ? (uint32_t)j : (uint32_t)g.ncols - 1;
+        const uint32_t n = fd_div(jc, g.fdP);
+        const uint32_t p = jc - n * g.P;
+        const uint32_t ho = fd_div(p, g.fdWo), wo = p - ho * g.Wo;
+        const int b_k = tid >> 7;
+        if (MODE == PC_FWD) {
+            // centre tap (2ho, 2wo) is always inside the image
+            bp = Bop + (size_t)n * g.C * g.HW + (size_t)(2 * ho) * g.W + 2 * wo + (size_t)b_k * g.HW;
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                const int hi = 2 * (int)ho - 1 + t / 3, wi = 2 * (int)wo - 1 + t % 3;
+                if (jin && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) mask |= 1u << t;
+            }
+            ntiles = 9 * (g.C / PC_BK);
+        } else {
+            const int cls = 3 - (int)blockIdx.y; // heaviest class (4 taps) first
+            ph = cls >> 1; pw = cls & 1;
+            ntw = pw ? 2 : 1;
+            ntaps = (ph ? 2 : 1) * ntw;
+            bp = Bop + (size_t)n * g.K * g.P + p + (size_t)b_k * g.P; // (a, b) itself is always a valid source pixel
+            for (int tt = 0; tt < ntaps; tt++) {
+                const int th = tt / ntw, tw = tt - th * ntw;
+                const int dh = (ph && th == 0) ? 1 : 0, dw = (pw && tw == 0) ? 1 : 0;
+                if (jin && (int)ho + dh < g.Ho && (int)wo + dw < g.Wo) mask |= 1u << tt;
+            }
+            ntiles = ntaps * (g.K / PC_BK);
+        }
+    } else {
+        wg_t = (int)(ct / (uint32_t)g.ctiles);
+        cblk = (int)(ct - (uint32_t)wg_t * g.ctiles) * 128;
+        wg_r = wg_t / 3; wg_s = wg_t - 3 * wg_r;
+        const int kbeg = (int)blockIdx.y * g.klen;
+        kend = min(g.N * g.P, kbeg + g.klen);
+        ntiles = (kend - kbeg + PC_BK - 1) / PC_BK;
+    }
+
+    pf4 ra4[4];
+    float ra[16], rb[16];
+    int sel_a = 1, sel_b = 1;   // whether the fetched A / B values are real (else stored as 0)
+    int ld_t = 0, ld_c0 = 0;    // next tile to fetch: tap (class tap) and first reduction channel
+    int ld_k0 = (MODE == PC_WGRAD) ? (int)blockIdx.y * g.klen : 0;
+
+    auto fetch = [&]() {
+        if (MODE == PC_FWD) {
+            const float *a = ap + (size_t)(ld_t * g.C + ld_c0) * g.K;
+#pragma unroll
+            for (int q = 0; q < 4; q++) ra4[q] = *(const pf4 *)(a + (size_t)(8 * q) * g.K);
+            const int r = (ld_t * 11) >> 5, s = ld_t - 3 * r;
+            sel_b = (mask >> ld_t) & 1;
+            const int toff = sel_b ? (r - 1) * g.W + (s - 1) : 0;
+            const float *b = bp + toff + (size_t)ld_c0 * g.HW;
+#pragma unroll
+            for (int q = 0; q < 16; q++) rb[q] = b[(size_t)(2 * q) * g.HW];
+            ld_c0 += PC_BK;
+            if (ld_c0 == g.C) { ld_c0 = 0; ld_t++; }
+        } else if (MODE == PC_DGRAD) {
+            const int th = ld_t / ntw, tw = ld_t - th * ntw;
+            const int r = ph ? (th ? 2 : 0) : 1, s = pw ? (tw ? 2 : 0) : 1;
+            const int dh = (ph && th == 0) ? 1 : 0, dw = (pw && tw == 0) ? 1 : 0;
+            const float *a = ap + (size_t)((3 * r + s) * g.K + ld_c0) * g.C;
+#pragma unroll
+            for (int q = 0; q < 4; q++) ra4[q] = *(const pf4 *)(a + (size_t)(8 * q) * g.C);
+            sel_b = (mask >> ld_t) & 1;
+            const int toff = sel_b ? dh * g.Wo + dw : 0;
+            const float *b = bp + toff + (size_t)ld_c0 * g.P;
+#pragma unroll
+            for (int q = 0; q < 16; q++) rb[q] = b[(size_t)(2 * q) * g.P];
+            ld_c0 += PC_BK;
+            if (ld_c0 == g.K) { ld_c0 = 0; ld_t++; }
+        } else {
+            const int kk = ld_k0 + (tid & 31);
+            sel_a = kk < kend;
+            const uint32_t kc = sel_a ? (uint32_t)kk : (uint32_t)kend - 1;
+            const uint32_t n = fd_div(kc, g.fdP);
+            const uint32_t p = kc - n * g.P;
+            const uint32_t ho = fd_div(p, g.fdWo), wo = p - ho * g.Wo;
+            const int hi = 2 * (int)ho - 1 + wg_r, wi = 2 * (int)wo - 1 + wg_s;
+            const int inb = hi >= 0 && hi < g.H && wi >= 0 && wi < g.W;
+            sel_b = sel_a && inb;
+            const int row = tid >> 5;
+            const float *a = Aop + (size_t)n * g.K * g.P + p + (size_t)(m0 + row) * g.P;
+            const float *b = Bop + (size_t)n * g.C * g.HW + (inb ? hi * g.W + wi : (int)(2 * ho) * g.W + (int)(2 * wo)) +
+                             (size_t)(cblk + row) * g.HW;
+#pragma unroll
+            for (int q = 0; q < 16; q++) ra[q] = a[(size_t)(8 * q) * g.P];
+#pragma unroll
+            for (int q = 0; q < 16; q++) rb[q] = b[(size_t)(8 * q) * g.HW];
+            ld_k0 += PC_BK;
+        }
+    };
+    auto stash = [&](int buf) {
+        float *as = As + buf * PC_BK * LDA, *bs = Bs + buf * PC_BK * LDB;
+        if (MODE == PC_WGRAD) {
+            const int kx = tid & 31, row = tid >> 5;
+#pragma unroll
+            for (int q = 0; q < 16; q++) as[kx * LDA + row + 8 * q] = sel_a ? ra[q] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; q++) bs[kx * LDB + row + 8 * q] = sel_b ? rb[q] : 0.f;
+        } else {
+            const int a_i = (tid & 31) * 4, a_k = tid >> 5;
+#pragma unroll
+            for (int q = 0; q < 4; q++) *(pf4 *)(as + (a_k + 8 * q) * LDA + a_i) = ra4[q];
+            const int bj = tid & 127, b_k = tid >> 7;
+#pragma unroll
+            for (int q = 0; q < 16; q++) bs[(b_k + 2 * q) * LDB + bj] = sel_b ? rb[q] : 0.f;
+        }
+    };
+
+    const int fr = lane & 31, fk = lane >> 5;
+    fetch();
+    stash(0);
+    __syncthreads();
+    for (int it = 0; it < ntiles; it++) {
+        const int buf = it & 1;
+        const bool more = it + 1 < ntiles;
+        if (more) fetch();
+        const float *as = As + buf * PC_BK * LDA + fk * LDA + wm * 64 + fr;
+        const float *bs = Bs + buf * PC_BK * LDB + fk * LDB + wn * 64 + fr;
+        // fragments of step k2+2 are read while the four MFMAs of step k2 run
+        float av[2][2], bv[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) { av[0][i] = as[i * 32]; bv[0][i] = bs[i * 32]; }
+#pragma unroll
+        for (int k2 = 0; k2 < PC_BK; k2 += 2) {
+            const int cur = (k2 >> 1) & 1;
+            if (k2 + 2 < PC_BK) {
+#pragma unroll
+                for (int i = 0; i < 2; i++) { av[cur ^ 1][i] = as[(k2 + 2) * LDA + i * 32]; bv[cur ^ 1][i] = bs[(k2 + 2) * LDB + i * 32]; }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulator layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) ----
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+        size_t coff, rstride;
+        bool cok;
+        if (MODE == PC_WGRAD) {
+            cok = true;
+            coff = ((size_t)((size_t)blockIdx.y * 9 + wg_t) * g.K) * g.C + cblk + wn * 64 + j * 32 + (lane & 31);
+            rstride = (size_t)g.C;
+        } else {
+            cok = col < g.ncols;
+            const uint32_t jc = cok ? (uint32_t)col : 0u;
+            const uint32_t n = fd_div(jc, g.fdP);
+            const uint32_t p = jc - n * g.P;
+            if (MODE == PC_FWD) { coff = (size_t)n * g.K * g.P + p; rstride = (size_t)g.P; }
+            else {
+                const uint32_t a = fd_div(p, g.fdWo), b = p - a * g.Wo;
+                coff = (size_t)n * g.C * g.HW + (size_t)(2 * a + ph) * g.W + 2 * b + pw;
+                rstride = (size_t)g.HW;
+            }
+        }
+        if (!cok) continue;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const size_t o = coff + (size_t)row * rstride;
+                float v = acc[i][j][r];
+                if (MODE == PC_DGRAD && addend) v += addend[o];
+                Out[o] = v;
+            }
+        }
+    }
+}
+
+// weights KCRS -> [t][c][k] (forward A operand) or [t][k][c] (dgrad A operand); 32 x 32 (k, c) tiles through LDS
+__global__ void __launch_bounds__(256)
+pconv_wt_kernel(const float *__restrict__ w, float *__restrict__ out, int K, int C, int to_tck) {
+    __shared__ float tile[32][9 * 32 + 1];
+    const int k0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    // row k of the tile: 32 channels x 9 taps = 288 contiguous floats of w
+    for (int e = threadIdx.x; e < 32 * 288; e += 256) {
+        const int kr = e / 288, x = e - kr * 288;
+        tile[kr][x] = w[((size_t)(k0 + kr) * C + c0) * 9 + x];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 9 * 32 * 32; e += 256) {
+        const int t = e >> 10, u = (e >> 5) & 31, v = e & 31; // v fastest = contiguous output dim
+        if (to_tck) out[((size_t)t * C + c0 + u) * K + k0 + v] = tile[v][u * 9 + t];
+        else out[((size_t)t * K + k0 + u) * C + c0 + v] = tile[u][v * 9 + t];
+    }
+}
+
+// dW[k][c][t] = sum_z part[z][t][k][c] in ascending z (deterministic)
+__global__ void __launch_bounds__(256)
+pconv_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, long KC, int splits) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= KC) return;
+    float s[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) s[t] = 0.f;
+    for (int z = 0; z < splits; z++)
+#pragma unroll
+        for (int t = 0; t < 9; t++) s[t] += part[((long)z * 9 + t) * KC + i];
+#pragma unroll
+    for (int t = 0; t < 9; t++) dw[i * 9 + t] = s[t];
+}
+
+static int pconv_enabled(void) {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("RESNET_MI_PCONV"); on = e ? atoi(e) : 1; }
+    return on;
+}
+// The MFMA path takes the projection shortcuts only: 3x3 / stride 2 with K >= 2C (the block's expansion happens in the
+// shortcut: 256->512, 512->1024, 1024->2048).  The bottleneck's own 3x3 convolutions (K == C, either stride) and the stem
+// stay on the direct VALU kernels.  RESNET_MI_PCONV=0 turns the path off, =2 also routes the K == C striding convs here
+// (measurement only).
+int mi_pconv_supported(int N, int C, int H, int K, int k, int stride) {
+    const int mode = pconv_enabled();
+    if (!mode) return 0;
+    if (k != 3 || stride != 2 || (H & 1) || H < 2) return 0;
+    if (C % 128 || K % 128 || C < 256 || K < 256) return 0;
+    if (mode == 1 && K < 2 * C) return 0;
+    if ((double)N * C * H * H >= 2147483648.0 || (double)N * K * (H / 2) * (H / 2) >= 2147483648.0) return 0;
+    return 1;
+}
+static int pconv_wgrad_splits(int N, int C, int H, int K) {
+    const long tiles = 9L * (C / 128) * (K / 128);
+    const long ksteps = ((long)N * (H / 2) * (H / 2) + PC_BK - 1) / PC_BK;
+    const long slots = 512; // 256 CUs x 2 resident workgroups
+    int best = 1;
+    double best_eff = 0;
+    for (int s = 1; s <= 32; s++) {
+        if (s > 1 && ksteps / s < 48) break;
+        const double waves = (double)tiles * s / slots;
+        const double eff = waves / (double)((long)((tiles * s + slots - 1) / slots));
+        if (eff > best_eff + 0.02) { best_eff = eff; best = s; }
+    }
+    return best;
+}
+size_t mi_pconv_part_floats(int N, int C, int H, int K) { return (size_t)pconv_wgrad_splits(N, C, H, K) * 9 * K * C; }
+
+static void pconv_geometry(PcArgs &g, int N, int C, int H, int K) {
+    g.N = N; g.C = C; g.K = K; g.H = H; g.W = H; g.Ho = H / 2; g.Wo = H / 2;
+    g.HW = H * H; g.P = g.Ho * g.Wo;
+    g.ncols = N * g.P;
+    g.fdP = make_fastdiv(g.P); g.fdWo = make_fastdiv(g.Wo);
+}
+template <int MODE>
+static int pconv_launch(hipStream_t st, dim3 grid, const float *A, const float *B, float *out, const float *addend, const PcArgs &g) {
+    constexpr int LD = (MODE == PC_WGRAD) ? 129 : 132;
+    constexpr size_t lds = (size_t)4 * PC_BK * LD * sizeof(float);
+    static int attr_set = 0;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)pconv_mfma_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            mi_record_error("pconv_mfma_kernel", "cannot raise the dynamic LDS limit");
+            return -1;
+        }
+        attr_set = 1;
+    }
+    hipLaunchKernelGGL((pconv_mfma_kernel<MODE>), grid, dim3(256), lds, st, A, B, out, addend, g);
+    return 0;
+}
+
+int mi_pconv_fwd(hipStream_t st, mid_workspace *ws, const float *x, const float *w, float *y, int N, int C, int H, int K) {
+    if (!ws || ws->wt_floats < (size_t)9 * C * K) { mi_record_error("mi_pconv_fwd", "workspace too small"); return -3; }
+    hipLaunchKernelGGL(pconv_wt_kernel, dim3(C / 32, K / 32), dim3(256), 0, st, w, ws->wt, K, C, 1);
+    MI_LAUNCH_CHECK("pconv_wt_kernel");
+    PcArgs g = {};
+    pconv_geometry(g, N, C, H, K);
+    g.mtiles = K / 128;
+    g.tiles = g.mtiles * mi_cdiv(g.ncols, 128);
+    g.fdM = make_fastdiv(g.mtiles);
+    mi_prof_begin(st, MI_FAM_PCONV, 2.0 * 9 * (double)g.ncols * C * K,
+                  4.0 * ((double)N * C * g.HW + 9.0 * C * K + (double)g.ncols * K));
+    const int rc = pconv_launch<PC_FWD>(st, dim3(g.tiles), ws->wt, x, y, nullptr, g);
+    mi_prof_end(st);
+    if (rc) return rc;
+    MI_LAUNCH_CHECK("pconv_mfma_kernel<fwd>");
+    return 0;
+}
+
+int mi_pconv_dgrad(hipStream_t st, mid_workspace *ws, const float *w, const float *dy, float *dx, const float *addend, int N,
+                   int C, int H, int K) {
+    if (!ws || ws->wt_floats < (size_t)9 * C * K) { mi_record_error("mi_pconv_dgrad", "workspace too small"); return -3; }
+    hipLaunchKernelGGL(pconv_wt_kernel, dim3(C / 32, K / 32), dim3(256), 0, st, w, ws->wt, K, C, 0);
+    MI_LAUNCH_CHECK("pconv_wt_kernel");
+    PcArgs g = {};
+    pconv_geometry(g, N, C, H, K);
+    g.mtiles = C / 128;
+    g.tiles = g.mtiles * mi_cdiv(g.ncols, 128);
+    g.fdM = make_fastdiv(g.mtiles);
+    mi_prof_begin(st, MI_FAM_PCONV, 2.0 * 9 * (double)g.ncols * C * K,
+                  4.0 * ((double)g.ncols * K + 9.0 * C * K + (double)N * C * g.HW * (addend ? 2 : 1)));
+    const int rc = pconv_launch<PC_DGRAD>(st, dim3(g.tiles, 4), ws->wt, dy, dx, addend, g);
+    mi_prof_end(st);
+    if (rc) return rc;
+    MI_LAUNCH_CHECK("pconv_mfma_kernel<dgrad>");
+    return 0;
+}
+
+int mi_pconv_wgrad(hipStream_t st, mid_workspace *ws, const float *x, const float *dy, float *dw, int N, int C, int H, int K) {
+    const int splits = pconv_wgrad_splits(N, C, H, K);
+    if (!ws || ws->part_floats < (size_t)splits * 9 * K * C) { mi_record_error("mi_pconv_wgrad", "workspace too small"); return -3; }
+    PcArgs g = {};
+    pconv_geometry(g, N, C, H, K);
+    g.mtiles = K / 128;
+    g.ctiles = C / 128;
+    g.tiles = g.mtiles * 9 * g.ctiles;
+    g.fdM = make_fastdiv(g.mtiles);
+    const int kd = N * g.P;
+    g.klen = mi_cdiv(mi_cdiv(kd, splits), PC_BK) * PC_BK;
+    const int used = mi_cdiv(kd, g.klen);
+    mi_prof_begin(st, MI_FAM_PCONV, 2.0 * 9 * (double)kd * C * K,
+                  4.0 * ((double)N * C * g.HW + (double)kd * K + 9.0 * C * K));
+    const int rc = pconv_launch<PC_WGRAD>(st, dim3(g.tiles, used), dy, x, ws->part, nullptr, g);
+    mi_prof_end(st);
+    if (rc) return rc;
+    MI_LAUNCH_CHECK("pconv_mfma_kernel<wgrad>");
+    const long KC = (long)K * C;
+    hipLaunchKernelGGL(pconv_wgrad_reduce_kernel, dim3(mi_cdiv(KC, 256)), dim3(256), 0, st, ws->part, dw, KC, used);
+    MI_LAUNCH_CHECK("pconv_wgrad_reduce_kernel");
+    return 0;
+}

@@ -12,7 +12,7 @@ void mi_record_error(const char *what, const char *detail);
     } while (0)
 
 // per-kernel-family timing with HIP events on the launch stream (bench.py roofline): begin/end bracket ONE launch
-enum { MI_FAM_DCONV = 0, MI_FAM_WGRAD = 1, MI_FAM_GEMM = 2, MI_FAM_BN = 3, MI_FAM_OTHER = 4, MI_FAM_COUNT = 5 };
+enum { MI_FAM_DCONV = 0, MI_FAM_WGRAD = 1, MI_FAM_GEMM = 2, MI_FAM_BN = 3, MI_FAM_OTHER = 4, MI_FAM_PCONV = 5, MI_FAM_COUNT = 6 };
 void mi_prof_begin(hipStream_t st, int fam, double flops, double bytes);
 void mi_prof_end(hipStream_t st);
 

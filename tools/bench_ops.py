@@ -74,7 +74,7 @@ def main():
                 if rc != 0:
                     raise SystemExit("%s %s failed: %s" % (name, op, L.mi_last_error().decode()))
             ms = 0.0
-            for fam in (0, 1, 2):
+            for fam in (0, 1, 2, 5):
                 n_, ms_, fl_, by_ = C.c_long(0), C.c_double(0), C.c_double(0), C.c_double(0)
                 L.mi_prof_get(fam, C.byref(n_), C.byref(ms_), C.byref(fl_), C.byref(by_))
                 ms += ms_.value
