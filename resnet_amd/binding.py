@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libresnet_mi.so")
+# RESNET_MI_LIB: load another build of the same library (kernel A/B experiments, tools/variant.sh)
+LIB_PATH = os.environ.get("RESNET_MI_LIB") or os.path.join(_HERE, "libresnet_mi.so")
 
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int)

@@ -149,18 +149,29 @@ gemm_mfma_kernel(const float *__restrict__ A, const float *__restrict__ B, float
         __syncthreads();
         if (k0 + G_BK < kend) load_tile(k0 + G_BK);
         const int fr = lane & 31, fk = lane >> 5;
+        // fragments of step k2+2 are read before the MFMAs of step k2 are issued (sched_barrier pins the order: the
+        // scheduler would otherwise sink the LDS reads to their use and expose their latency every step)
+        float av[2][TM], bv[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++) av[0][i] = As[fk * LDA + wm * WM + i * 32 + fr];
+#pragma unroll
+        for (int j = 0; j < TN; j++) bv[0][j] = Bs[fk * LDB + wn * WN + j * 32 + fr];
 #pragma unroll
         for (int k2 = 0; k2 < G_BK; k2 += 2) {
-            float av[TM], bv[TN];
+            const int cur = (k2 >> 1) & 1;
+            if (k2 + 2 < G_BK) {
 #pragma unroll
-            for (int i = 0; i < TM; i++) av[i] = As[(k2 + fk) * LDA + wm * WM + i * 32 + fr];
+                for (int i = 0; i < TM; i++) av[cur ^ 1][i] = As[(k2 + 2 + fk) * LDA + wm * WM + i * 32 + fr];
 #pragma unroll
-            for (int j = 0; j < TN; j++) bv[j] = Bs[(k2 + fk) * LDB + wn * WN + j * 32 + fr];
+                for (int j = 0; j < TN; j++) bv[cur ^ 1][j] = Bs[(k2 + 2 + fk) * LDB + wn * WN + j * 32 + fr];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int j = 0; j < TN; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 

@@ -40,6 +40,9 @@ struct PcArgs {
 };
 
 #define PC_BK 32
+#ifndef PC_ABLATE
+#define PC_ABLATE 0 /* experiments only: 1 = no global loads / LDS stores after the first tile, 2 = also no barrier, 3 = no LDS stores, 4 = no global loads */
+#endif
 
 template <int MODE>
 __global__ void __launch_bounds__(256)
@@ -75,8 +78,10 @@ pconv_mfma_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, 
     // ---- per-thread staging state ----
     // FWD / DGRAD: A = 4 x float4 along M (rows a_k + 8q), B = 16 gathered scalars of ONE column (rows b_k + 2q)
     // WGRAD:       A, B = 16 scalars each of ONE reduction index (tid & 31), rows/cols (tid >> 5) + 8q
-    const float *ap = nullptr;
-    const float *bp = nullptr;
+    // Global addresses are a wave-uniform 64-bit base (SGPRs, advanced on the scalar unit) plus a 32-bit per-lane byte
+    // offset: the loads take the `global_load v, v_off, s[base]` form -- no 64-bit vector address arithmetic in the loop
+    // and half the address payload per load.  Every tensor is < 2^32 bytes (mi_pconv_supported).
+    uint32_t a_lane = 0, b_lane = 0;
     uint32_t mask = 0; // FWD: bit t = tap t in the image; DGRAD: bit tt = class tap tt in the image
     int ph = 0, pw = 0, ntw = 1, ntaps = 1;
     int wg_t = 0, wg_r = 0, wg_s = 0, cblk = 0, kend = 0;
@@ -84,7 +89,7 @@ pconv_mfma_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, 
     if (MODE == PC_FWD || MODE == PC_DGRAD) {
         const int a_i = (tid & 31) * 4, a_k = tid >> 5;
         const int Mdim = MODE == PC_FWD ? g.K : g.C;
-        ap = Aop + (size_t)a_k * Mdim + m0 + a_i;
+        a_lane = (uint32_t)(a_k * Mdim + a_i) * 4u;
         const int j = n0 + (tid & 127);
         const bool jin = j < g.ncols;
         const uint32_t jc = jin ? (uint32_t)j : (uint32_t)g.ncols - 1;
@@ -94,7 +99,7 @@ pconv_mfma_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, 
         const int b_k = tid >> 7;
         if (MODE == PC_FWD) {
             // centre tap (2ho, 2wo) is always inside the image
-            bp = Bop + (size_t)n * g.C * g.HW + (size_t)(2 * ho) * g.W + 2 * wo + (size_t)b_k * g.HW;
+            b_lane = (uint32_t)(n * g.C * g.HW + (2 * ho) * g.W + 2 * wo + b_k * g.HW) * 4u;
 #pragma unroll
             for (int t = 0; t < 9; t++) {
                 const int hi = 2 * (int)ho - 1 + t / 3, wi = 2 * (int)wo - 1 + t % 3;
@@ -106,7 +111,7 @@ pconv_mfma_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, 
             ph = cls >> 1; pw = cls & 1;
             ntw = pw ? 2 : 1;
             ntaps = (ph ? 2 : 1) * ntw;
-            bp = Bop + (size_t)n * g.K * g.P + p + (size_t)b_k * g.P; // (a, b) itself is always a valid source pixel
+            b_lane = (uint32_t)(n * g.K * g.P + p + b_k * g.P) * 4u; // (a, b) itself is always a valid source pixel
             for (int tt = 0; tt < ntaps; tt++) {
                 const int th = tt / ntw, tw = tt - th * ntw;
                 const int dh = (ph && th == 0) ? 1 : 0, dw = (pw && tw == 0) ? 1 : 0;
@@ -125,84 +130,120 @@ pconv_mfma_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, 
 
     pf4 ra4[4];
     float ra[16], rb[16];
-    int sel_a = 1, sel_b = 1;   // whether the fetched A / B values are real (else stored as 0)
+    int sel_a = 1, sel_b = 1;   // whether the values held in ra / rb are real (else they are stored to LDS as 0)
     int ld_t = 0, ld_c0 = 0;    // next tile to fetch: tap (class tap) and first reduction channel
     int ld_k0 = (MODE == PC_WGRAD) ? (int)blockIdx.y * g.klen : 0;
+    const char *fa = nullptr, *fb = nullptr; // wave-uniform bases of the tile being fetched (set by part 0)
+    uint32_t fa_lane = 0, fb_lane = 0;       // per-lane byte offsets of the tile being fetched
+    auto ldg = [](const char *ubase, uint32_t lane_off) -> float { return *(const float *)(ubase + lane_off); };
+    auto ldg4 = [](const char *ubase, uint32_t lane_off) -> pf4 { return *(const pf4 *)(ubase + lane_off); };
 
-    auto fetch = [&]() {
-        if (MODE == PC_FWD) {
-            const float *a = ap + (size_t)(ld_t * g.C + ld_c0) * g.K;
-#pragma unroll
-            for (int q = 0; q < 4; q++) ra4[q] = *(const pf4 *)(a + (size_t)(8 * q) * g.K);
-            const int r = (ld_t * 11) >> 5, s = ld_t - 3 * r;
-            sel_b = (mask >> ld_t) & 1;
-            const int toff = sel_b ? (r - 1) * g.W + (s - 1) : 0;
-            const float *b = bp + toff + (size_t)ld_c0 * g.HW;
-#pragma unroll
-            for (int q = 0; q < 16; q++) rb[q] = b[(size_t)(2 * q) * g.HW];
-            ld_c0 += PC_BK;
-            if (ld_c0 == g.C) { ld_c0 = 0; ld_t++; }
-        } else if (MODE == PC_DGRAD) {
-            const int th = ld_t / ntw, tw = ld_t - th * ntw;
-            const int r = ph ? (th ? 2 : 0) : 1, s = pw ? (tw ? 2 : 0) : 1;
-            const int dh = (ph && th == 0) ? 1 : 0, dw = (pw && tw == 0) ? 1 : 0;
-            const float *a = ap + (size_t)((3 * r + s) * g.K + ld_c0) * g.C;
-#pragma unroll
-            for (int q = 0; q < 4; q++) ra4[q] = *(const pf4 *)(a + (size_t)(8 * q) * g.C);
-            sel_b = (mask >> ld_t) & 1;
-            const int toff = sel_b ? dh * g.Wo + dw : 0;
-            const float *b = bp + toff + (size_t)ld_c0 * g.P;
-#pragma unroll
-            for (int q = 0; q < 16; q++) rb[q] = b[(size_t)(2 * q) * g.P];
-            ld_c0 += PC_BK;
-            if (ld_c0 == g.K) { ld_c0 = 0; ld_t++; }
+    // Staging is cut into 8 parts so that it can be spread over the 16 MFMA groups of a tile: the LDS stores of the tile
+    // held in registers go with groups 0-7, the global loads of the tile after it (into the same registers) with groups 8-15.
+    auto fetch_part = [&](const int p) {
+        if (MODE == PC_FWD || MODE == PC_DGRAD) {
+            if (p == 0) {
+                // past the last tile (the two drain iterations fetch unconditionally) the last tap is simply read again
+                if (MODE == PC_FWD) {
+                    const int t = min(ld_t, 8);
+                    fa = (const char *)(Aop + (size_t)(t * g.C + ld_c0) * g.K + m0);
+                    const int r = (t * 11) >> 5, s = t - 3 * r;
+                    sel_b = (mask >> t) & 1;
+                    fb = (const char *)(Bop + (size_t)ld_c0 * g.HW);
+                    fb_lane = b_lane + (uint32_t)(sel_b * ((r - 1) * g.W + (s - 1)) * 4); // out-of-image tap: centre pixel, stored as 0
+                    ld_c0 += PC_BK;
+                    if (ld_c0 == g.C) { ld_c0 = 0; ld_t++; }
+                } else {
+                    const int t = min(ld_t, ntaps - 1);
+                    const int th = pw ? t >> 1 : t, tw = pw ? t & 1 : 0;
+                    const int r = ph ? 2 * th : 1, s = pw ? 2 * tw : 1;
+                    const int dh = ph & (th ^ 1), dw = pw & (tw ^ 1);
+                    fa = (const char *)(Aop + (size_t)((3 * r + s) * g.K + ld_c0) * g.C + m0);
+                    sel_b = (mask >> t) & 1;
+                    fb = (const char *)(Bop + (size_t)ld_c0 * g.P);
+                    fb_lane = b_lane + (uint32_t)(sel_b * (dh * g.Wo + dw) * 4);
+                    ld_c0 += PC_BK;
+                    if (ld_c0 == g.K) { ld_c0 = 0; ld_t++; }
+                }
+            }
+            const size_t bstride = (MODE == PC_FWD ? (size_t)g.HW : (size_t)g.P) * 4;
+            const size_t astride = (MODE == PC_FWD ? (size_t)g.K : (size_t)g.C) * 4;
+            rb[2 * p] = ldg(fb + (size_t)(4 * p) * bstride, fb_lane);
+            rb[2 * p + 1] = ldg(fb + (size_t)(4 * p + 2) * bstride, fb_lane);
+            if ((p & 1) == 0) ra4[p >> 1] = ldg4(fa + (size_t)(4 * p) * astride, a_lane);
         } else {
-            const int kk = ld_k0 + (tid & 31);
-            sel_a = kk < kend;
-            const uint32_t kc = sel_a ? (uint32_t)kk : (uint32_t)kend - 1;
-            const uint32_t n = fd_div(kc, g.fdP);
-            const uint32_t p = kc - n * g.P;
-            const uint32_t ho = fd_div(p, g.fdWo), wo = p - ho * g.Wo;
-            const int hi = 2 * (int)ho - 1 + wg_r, wi = 2 * (int)wo - 1 + wg_s;
-            const int inb = hi >= 0 && hi < g.H && wi >= 0 && wi < g.W;
-            sel_b = sel_a && inb;
-            const int row = tid >> 5;
-            const float *a = Aop + (size_t)n * g.K * g.P + p + (size_t)(m0 + row) * g.P;
-            const float *b = Bop + (size_t)n * g.C * g.HW + (inb ? hi * g.W + wi : (int)(2 * ho) * g.W + (int)(2 * wo)) +
-                             (size_t)(cblk + row) * g.HW;
-#pragma unroll
-            for (int q = 0; q < 16; q++) ra[q] = a[(size_t)(8 * q) * g.P];
-#pragma unroll
-            for (int q = 0; q < 16; q++) rb[q] = b[(size_t)(8 * q) * g.HW];
-            ld_k0 += PC_BK;
+            if (p == 0) {
+                const int kk = ld_k0 + (tid & 31);
+                sel_a = kk < kend;
+                uint32_t kc = sel_a ? (uint32_t)kk : (uint32_t)kend - 1;
+                if (PC_ABLATE == 5) kc &= 1023; /* experiment: every block streams the same L2-resident slice */
+                const uint32_t n = fd_div_ge2(kc, g.fdP); // P, Wo >= 2 (mi_pconv_supported); no branches in here
+                const uint32_t pp = kc - n * g.P;
+                const uint32_t ho = fd_div_ge2(pp, g.fdWo), wo = pp - ho * g.Wo;
+                const int hi = 2 * (int)ho - 1 + wg_r, wi = 2 * (int)wo - 1 + wg_s;
+                const int inb = (int)((uint32_t)hi < (uint32_t)g.H) & (int)((uint32_t)wi < (uint32_t)g.W);
+                sel_b = sel_a & inb;
+                const uint32_t row = (uint32_t)tid >> 5;
+                fa = (const char *)(Aop + (size_t)m0 * g.P);
+                fb = (const char *)(Bop + (size_t)cblk * g.HW);
+                fa_lane = (n * (uint32_t)(g.K * g.P) + pp + row * g.P) * 4u;
+                const uint32_t pix = inb ? (uint32_t)(hi * g.W + wi) : (2 * ho) * g.W + 2 * wo;
+                fb_lane = (n * (uint32_t)(g.C * g.HW) + pix + row * g.HW) * 4u;
+                ld_k0 += PC_BK;
+            }
+            ra[2 * p] = ldg(fa + (size_t)(16 * p) * g.P * 4, fa_lane);
+            ra[2 * p + 1] = ldg(fa + (size_t)(16 * p + 8) * g.P * 4, fa_lane);
+            rb[2 * p] = ldg(fb + (size_t)(16 * p) * g.HW * 4, fb_lane);
+            rb[2 * p + 1] = ldg(fb + (size_t)(16 * p + 8) * g.HW * 4, fb_lane);
         }
     };
-    auto stash = [&](int buf) {
+    auto stash_part = [&](const int buf, const int p) {
         float *as = As + buf * PC_BK * LDA, *bs = Bs + buf * PC_BK * LDB;
         if (MODE == PC_WGRAD) {
             const int kx = tid & 31, row = tid >> 5;
-#pragma unroll
-            for (int q = 0; q < 16; q++) as[kx * LDA + row + 8 * q] = sel_a ? ra[q] : 0.f;
-#pragma unroll
-            for (int q = 0; q < 16; q++) bs[kx * LDB + row + 8 * q] = sel_b ? rb[q] : 0.f;
+            as[kx * LDA + row + 16 * p] = sel_a ? ra[2 * p] : 0.f;
+            as[kx * LDA + row + 16 * p + 8] = sel_a ? ra[2 * p + 1] : 0.f;
+            bs[kx * LDB + row + 16 * p] = sel_b ? rb[2 * p] : 0.f;
+            bs[kx * LDB + row + 16 * p + 8] = sel_b ? rb[2 * p + 1] : 0.f;
         } else {
-            const int a_i = (tid & 31) * 4, a_k = tid >> 5;
-#pragma unroll
-            for (int q = 0; q < 4; q++) *(pf4 *)(as + (a_k + 8 * q) * LDA + a_i) = ra4[q];
             const int bj = tid & 127, b_k = tid >> 7;
-#pragma unroll
-            for (int q = 0; q < 16; q++) bs[(b_k + 2 * q) * LDB + bj] = sel_b ? rb[q] : 0.f;
+            bs[(b_k + 4 * p) * LDB + bj] = sel_b ? rb[2 * p] : 0.f;
+            bs[(b_k + 4 * p + 2) * LDB + bj] = sel_b ? rb[2 * p + 1] : 0.f;
+            if ((p & 1) == 0) {
+                const int a_i = (tid & 31) * 4, a_k = tid >> 5;
+                *(pf4 *)(as + (a_k + 4 * p) * LDA + a_i) = ra4[p >> 1];
+            }
         }
     };
 
     const int fr = lane & 31, fk = lane >> 5;
-    fetch();
-    stash(0);
+#pragma unroll
+    for (int p = 0; p < 8; p++) fetch_part(p);
+#pragma unroll
+    for (int p = 0; p < 8; p++) stash_part(0, p);
+#pragma unroll
+    for (int p = 0; p < 8; p++) fetch_part(p);
+    // The loop is entered with NO load in flight: every register of tile 1 passes through an empty asm, so the compiler
+    // drains vmcnt here, once.  Otherwise the vmcnt each LDS store of the loop waits for is the minimum over both ways
+    // into the loop, and the prologue's loads (which the compiler reorders and sinks) made every store drain half of the
+    // loads in flight.
+    if (MODE == PC_WGRAD) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) asm volatile("" : "+v"(ra[q]), "+v"(rb[q]));
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; q++) asm volatile("" : "+v"(rb[q]));
+#pragma unroll
+        for (int q = 0; q < 4; q++) asm volatile("" : "+v"(ra4[q]));
+    }
     __syncthreads();
     for (int it = 0; it < ntiles; it++) {
         const int buf = it & 1;
-        const bool more = it + 1 < ntiles;
-        if (more) fetch();
+        // The registers hold tile it+1: it goes to the other buffer, then the registers are refilled with tile it+2.  Both
+        // are UNCONDITIONAL (in the last two iterations they move data nobody reads): under a branch the compiler must
+        // assume the loads may still be pending where the registers are next written and drains vmcnt in every part.
+        constexpr bool st = PC_ABLATE != 1 && PC_ABLATE != 2 && PC_ABLATE != 3;
+        constexpr bool ft = PC_ABLATE != 1 && PC_ABLATE != 2 && PC_ABLATE != 4;
         const float *as = As + buf * PC_BK * LDA + fk * LDA + wm * 64 + fr;
         const float *bs = Bs + buf * PC_BK * LDB + fk * LDB + wn * 64 + fr;
         // fragments of step k2+2 are read while the four MFMAs of step k2 run
@@ -211,19 +252,22 @@ pconv_mfma_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, 
         for (int i = 0; i < 2; i++) { av[0][i] = as[i * 32]; bv[0][i] = bs[i * 32]; }
 #pragma unroll
         for (int k2 = 0; k2 < PC_BK; k2 += 2) {
-            const int cur = (k2 >> 1) & 1;
+            const int cur = (k2 >> 1) & 1, grp = k2 >> 1;
             if (k2 + 2 < PC_BK) {
 #pragma unroll
                 for (int i = 0; i < 2; i++) { av[cur ^ 1][i] = as[(k2 + 2) * LDA + i * 32]; bv[cur ^ 1][i] = bs[(k2 + 2) * LDB + i * 32]; }
             }
+            __builtin_amdgcn_sched_barrier(0); // keep the reads ahead of the MFMAs (the scheduler would sink them to their use)
+            if (grp < 8) { if (st) stash_part(buf ^ 1, grp); }
+            else { if (ft) fetch_part(grp - 8); }
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
                 for (int j = 0; j < 2; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) stash(buf ^ 1);
-        __syncthreads();
+        if (PC_ABLATE < 2) __syncthreads();
     }
 
     // ---- epilogue: accumulator layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) ----
@@ -308,10 +352,10 @@ static int pconv_enabled(void) {
 int mi_pconv_supported(int N, int C, int H, int K, int k, int stride) {
     const int mode = pconv_enabled();
     if (!mode) return 0;
-    if (k != 3 || stride != 2 || (H & 1) || H < 2) return 0;
+    if (k != 3 || stride != 2 || (H & 1) || H < 4) return 0;
     if (C % 128 || K % 128 || C < 256 || K < 256) return 0;
     if (mode == 1 && K < 2 * C) return 0;
-    if ((double)N * C * H * H >= 2147483648.0 || (double)N * K * (H / 2) * (H / 2) >= 2147483648.0) return 0;
+    if ((double)N * C * H * H >= 1073741824.0 || (double)N * K * (H / 2) * (H / 2) >= 1073741824.0) return 0; /* 32-bit byte offsets */
     return 1;
 }
 static int pconv_wgrad_splits(int N, int C, int H, int K) {

@@ -44,6 +44,11 @@ static inline FastDiv make_fastdiv(uint32_t d) {
     f.magic = (uint32_t)(((1ull << 32) * ((1ull << l) - f.d)) / f.d + 1);
     return f;
 }
+// branch-free form for divisors known to be >= 2 (inside software-pipelined loops, where a branch splits the schedule)
+__host__ __device__ __forceinline__ uint32_t fd_div_ge2(uint32_t n, const FastDiv f) {
+    uint32_t t = (uint32_t)(((uint64_t)n * f.magic) >> 32);
+    return (t + ((n - t) >> 1)) >> f.shift;
+}
 __host__ __device__ __forceinline__ uint32_t fd_div(uint32_t n, const FastDiv f) {
     if (f.d == 1) return n;
     uint32_t t = (uint32_t)(((uint64_t)n * f.magic) >> 32);
