@@ -22,9 +22,9 @@ sys.path.insert(0, ROOT)
 
 FP32_PEAK_TFLOPS = 157.3  # gfx950 fp32: vector FMA rate == fp32 MFMA rate (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
-FAMILIES = {0: "direct conv 3x3/7x7 fwd+dgrad (dconv_kernel, VALU)", 1: "direct conv wgrad (wgrad_kernel, VALU)",
-            2: "1x1 conv / FC GEMM (gemm_mfma_kernel, fp32 MFMA)", 3: "batch norm fwd+bwd",
-            5: "3x3-s2 projection conv fwd+dgrad+wgrad (pconv_mfma_kernel, implicit GEMM on fp32 MFMA)"}
+FAMILIES = {0: "direct conv 7x7 stem / untiled 3x3 fwd+dgrad (dconv_kernel, VALU)", 1: "direct conv wgrad (wgradC/wgrad_kernel, VALU)",
+            2: "1x1 conv / FC GEMM (igemm_kernel<*,1,1,*> / gemm_mfma_kernel, fp32 MFMA)", 3: "batch norm fwd+bwd",
+            5: "3x3 conv fwd+dgrad+wgrad incl. the 3x3-s2 projections (igemm_kernel<*,3,*,*>, implicit GEMM on fp32 MFMA)"}
 
 
 def cpu_baseline(seconds_budget=30.0):

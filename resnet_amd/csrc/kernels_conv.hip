@@ -655,21 +655,24 @@ int mi_conv1x1_dgrad(hipStream_t st, const float *w, const float *dy, float *dx,
 int mi_conv1x1_wgrad(hipStream_t st, mid_workspace *ws, const float *x, const float *dy, float *dw, int N, int C, int P,
                      int K);
 size_t mi_conv1x1_wgrad_part_floats(int N, int C, int P, int K);
-// kernels_pconv.hip: the GEMM-shaped 3x3/s2 projection shortcuts as an implicit GEMM on fp32 MFMA
-int mi_pconv_supported(int N, int C, int H, int K, int k, int stride);
-size_t mi_pconv_part_floats(int N, int C, int H, int K);
-int mi_pconv_fwd(hipStream_t st, mid_workspace *ws, const float *x, const float *w, float *y, int N, int C, int H, int K);
-int mi_pconv_dgrad(hipStream_t st, mid_workspace *ws, const float *w, const float *dy, float *dx, const float *addend, int N,
-                   int C, int H, int K);
-int mi_pconv_wgrad(hipStream_t st, mid_workspace *ws, const float *x, const float *dy, float *dw, int N, int C, int H, int K);
+// kernels_igemm.hip: implicit GEMM on fp32 MFMA (1x1 layers, the 3x3/s2 projection shortcuts; policy in mi_igemm_supported)
+enum { IGOP_FWD = 0, IGOP_DGRAD = 1, IGOP_WGRAD = 2 };
+int mi_igemm_supported(int op, int N, int C, int H, int K, int k, int stride);
+size_t mi_igemm_part_floats(int N, int C, int H, int K, int k, int stride);
+int mi_igemm_fwd(hipStream_t st, mid_workspace *ws, const float *x, const float *w, float *y, int N, int C, int H, int K, int k,
+                 int stride);
+int mi_igemm_dgrad(hipStream_t st, mid_workspace *ws, const float *w, const float *dy, float *dx, const float *addend, int N,
+                   int C, int H, int K, int k, int stride);
+int mi_igemm_wgrad(hipStream_t st, mid_workspace *ws, const float *x, const float *dy, float *dw, int N, int C, int H, int K, int k,
+                   int stride);
 
 extern "C" {
 
-size_t mid_conv_ws_wt_floats(int C, int K, int k) { return k == 1 ? 0 : (size_t)k * k * C * K; }
+size_t mid_conv_ws_wt_floats(int C, int K, int k) { return (size_t)k * k * C * K; } /* 1x1 forward re-lays W to [c][k] too */
 
 size_t mid_conv_ws_part_floats(int N, int C, int H, int K, int k, int stride) {
+    if (mi_igemm_supported(IGOP_WGRAD, N, C, H, K, k, stride)) return mi_igemm_part_floats(N, C, H, K, k, stride);
     if (k == 1) return mi_conv1x1_wgrad_part_floats(N, C, H * H, K);
-    if (mi_pconv_supported(N, C, H, K, k, stride)) return mi_pconv_part_floats(N, C, H, K);
     WbPlan pb;
     if (!wgradB_plan(N, C, H, K, k, stride, &pb)) return pb.splits > 1 ? (size_t)pb.splits * K * C * 9 : 0;
     WgPlan p;
@@ -680,8 +683,8 @@ size_t mid_conv_ws_part_floats(int N, int C, int H, int K, int k, int stride) {
 int mid_conv_fwd(mid_stream s, mid_workspace *ws, const float *x, const float *w, float *y, int N, int C, int H, int K,
                  int k, int stride) {
     hipStream_t st = (hipStream_t)s;
+    if (mi_igemm_supported(IGOP_FWD, N, C, H, K, k, stride)) return mi_igemm_fwd(st, ws, x, w, y, N, C, H, K, k, stride);
     if (k == 1 && stride == 1) return mi_conv1x1_fwd(st, x, w, y, N, C, H * H, K);
-    if (mi_pconv_supported(N, C, H, K, k, stride)) return mi_pconv_fwd(st, ws, x, w, y, N, C, H, K);
     if (!((k == 3 && (stride == 1 || stride == 2)) || (k == 7 && stride == 2)) || H % stride) {
         mi_record_error("mid_conv_fwd", "unsupported kernel/stride");
         return -2;
@@ -700,8 +703,8 @@ int mid_conv_fwd(mid_stream s, mid_workspace *ws, const float *x, const float *w
 int mid_conv_dgrad(mid_stream s, mid_workspace *ws, const float *w, const float *dy, float *dx, const float *addend,
                    int N, int C, int H, int K, int k, int stride) {
     hipStream_t st = (hipStream_t)s;
+    if (mi_igemm_supported(IGOP_DGRAD, N, C, H, K, k, stride)) return mi_igemm_dgrad(st, ws, w, dy, dx, addend, N, C, H, K, k, stride);
     if (k == 1 && stride == 1) return mi_conv1x1_dgrad(st, w, dy, dx, addend, N, C, H * H, K);
-    if (mi_pconv_supported(N, C, H, K, k, stride)) return mi_pconv_dgrad(st, ws, w, dy, dx, addend, N, C, H, K);
     if (k != 3 || (stride != 1 && stride != 2) || H % stride) { mi_record_error("mid_conv_dgrad", "unsupported kernel/stride"); return -2; }
     if (!ws || ws->wt_floats < (size_t)9 * C * K) { mi_record_error("mid_conv_dgrad", "workspace too small"); return -3; }
     const int Ho = H / stride;
@@ -769,8 +772,8 @@ int mid_conv_dgrad(mid_stream s, mid_workspace *ws, const float *w, const float 
 int mid_conv_wgrad(mid_stream s, mid_workspace *ws, const float *x, const float *dy, float *dw, int N, int C, int H,
                    int K, int k, int stride) {
     hipStream_t st = (hipStream_t)s;
+    if (mi_igemm_supported(IGOP_WGRAD, N, C, H, K, k, stride)) return mi_igemm_wgrad(st, ws, x, dy, dw, N, C, H, K, k, stride);
     if (k == 1 && stride == 1) return mi_conv1x1_wgrad(st, ws, x, dy, dw, N, C, H * H, K);
-    if (mi_pconv_supported(N, C, H, K, k, stride)) return mi_pconv_wgrad(st, ws, x, dy, dw, N, C, H, K);
     WbPlan pb;
     if (!wgradB_plan(N, C, H, K, k, stride, &pb)) {
         const size_t wsz9 = (size_t)K * C * 9;

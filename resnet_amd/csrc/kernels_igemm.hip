@@ -1,0 +1,548 @@
+// kernels_igemm.hip -- convolutions as an im2col-free implicit GEMM on the CDNA4 matrix cores, fp32
+// (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate).
+//
+// Which layers come here is a policy of mi_igemm_supported() (RESNET_MI_IGEMM, see there).  By default:
+//   * every 3x3 convolution whose channel counts tile, forward / dgrad / wgrad, stride 1 or 2 -- among them the reference's
+//     PROJECTION shortcuts, which are 3x3 / stride-2 / pad-1 (resnet.cu:884-889, 1693-1700), not the usual 1x1:
+//     256->512 @56, 512->1024 @28, 1024->2048 @14 hold 57% of the network's multiply-adds;
+//   * the weight gradients of the 1x1 convolutions.
+// The stem (C = 3), layers whose channels do not tile and, with RESNET_MI_IGEMM=1, the bottleneck's own 3x3 convolutions
+// run on the direct VALU kernels of kernels_conv.hip; 1x1 forward / dgrad on gemm_mfma_kernel.
+// The "im2col" matrix exists only as the 32 x 128 tile of LDS that the current k-step multiplies, gathered straight from
+// the NCHW tensor.
+//
+//   forward  Y[n][k][ho][wo]  = sum_{t=(r,s)} sum_c W[k][c][r][s] X[n][c][S*ho-pad+r][S*wo-pad+s]
+//            M = K (out channels), N = (n,ho,wo), reduction (t,c) tap-major; A = weights re-laid [t][c][k]
+//   dgrad    S=1: dX[n][c][h][w] = sum_{t,k} W[k][c][r][s] dY[n][k][h+pad-r][w+pad-s]
+//            S=2: dX[n][c][2a+ph][2b+pw] = sum over the 1/2/2/4 taps that reach parity class (ph,pw); classes = blockIdx.y
+//            M = C, N = (n, pixel), reduction (tap,k); A = weights re-laid [t][k][c] (1x1: the KC tensor itself)
+//   wgrad    dW[k][c][t] = sum_{n,ho,wo} dY[n][k][ho][wo] X[n][c][S*ho-pad+r][S*wo-pad+s]
+//            M = K, N = (t,c), reduction (n,ho,wo) split over blockIdx.y; partials [split][t][k][c], reduced (and
+//            transposed to KCRS) by igemm_wgrad_reduce_kernel in a fixed order (deterministic)
+//
+// Tile BM x 128 x 32 with BM = 128 (4 waves of 64x64) or 64 (4 waves of 64x32), 256 threads.  LDS double-buffered, one
+// barrier per k-step.  Staging is software-pipelined over the 16 MFMA groups of a k-step: the LDS stores of tile i+1 (held
+// in registers) ride with groups 0-7, the global loads of tile i+2 with groups 8-15.  What made this fast, in order of
+// effect (b7 projection wgrad 96 -> 117 TFLOP/s; MFMA-only ceiling of this loop 138):
+//   1. loads as `global_load v, v_off32, s[base]`: wave-uniform 64-bit base advanced on the scalar unit + 32-bit per-lane
+//      byte offset.  Per-lane 64-bit addresses cost two v_lshl_add_u64 per load and twice the address payload; VMEM issue,
+//      not memory latency, was the limiter (the same loads from an L2-resident slice were no faster);
+//   2. stores and loads UNCONDITIONAL (the last two iterations move data nobody reads) and the loop entered with no load
+//      in flight (one drain after the prologue): the vmcnt a store waits for is the minimum over all paths into it, and a
+//      branch or the compiler-reordered prologue loads made every store drain most of the loads in flight;
+//   3. no branches in the loop body at all (fd_div_ge2, arithmetic selects);
+//   4. fragments of step k2+2 read ahead of the MFMAs of step k2 (sched_barrier pins it).
+// Out-of-image taps load from the (always valid) centre tap's address and are zeroed when stored to LDS, so no load is
+// predicated.  Block ids are re-mapped so that each XCD walks a contiguous range of tiles, M-tiles fastest: the blocks that
+// share a gathered pixel tile share an L2.
+#include "mi_common.hpp"
+#include "mi_device.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float pf4 __attribute__((ext_vector_type(4)));
+
+enum { IG_FWD = 0, IG_DGRAD = 1, IG_WGRAD = 2 };
+
+struct IgArgs {
+    int N, C, K, H, W, Ho, Wo; // KS x KS, stride S, pad KS/2: Ho = H/S, Wo = W/S
+    int HW, P;                 // H*W, Ho*Wo
+    int ncols;                 // fwd/dgrad: N*P columns
+    int mtiles;                // number of BM-row tiles
+    int tiles;                 // mtiles * column tiles: blocks per blockIdx.y
+    int ctiles;                // wgrad: C/128
+    int klen;                  // wgrad: reduction length per split (multiple of 32)
+    FastDiv fdP, fdWo, fdM;    // fdM: division by mtiles
+};
+
+#define IG_BK 32
+#ifndef IG_ABLATE
+#define IG_ABLATE 0 /* experiments only: 1 = no staging after the first tile, 4 = no global loads */
+#endif
+
+template <int MODE, int KS, int S, int WMW>
+__global__ void __launch_bounds__(256)
+igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float *__restrict__ Out,
+             const float *__restrict__ addend, const IgArgs g) {
+    constexpr int BM = 64 * WMW;                 // rows per block
+    constexpr int TN = WMW == 2 ? 2 : 1;         // 32-column MFMA tiles per wave (wave tile 64 x 32*TN)
+    constexpr int WNC = 32 * TN;                 // columns per wave
+    constexpr int T = KS * KS, PAD = KS / 2;
+    constexpr int LDA = (MODE == IG_WGRAD) ? BM + 1 : BM + 4; // +1: conflict-free transposed scalar stores; +4: 16-B rows
+    constexpr int LDB = (MODE == IG_WGRAD) ? 129 : 132;
+    constexpr int NA4 = BM / 32;                 // fwd/dgrad: float4 loads of A per thread and tile
+    constexpr int NAS = BM / 8;                  // wgrad: scalar loads of A per thread and tile
+    extern __shared__ __attribute__((aligned(16))) float ig_smem[];
+    float *As = ig_smem;                   // [2][32][LDA]
+    float *Bs = ig_smem + 2 * IG_BK * LDA; // [2][32][LDB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = WMW == 2 ? wave >> 1 : 0, wn = WMW == 2 ? wave & 1 : wave;
+
+    // ---- block -> tile (XCD-contiguous, M-tiles fastest) ----
+    uint32_t L = blockIdx.x;
+    {
+        const uint32_t per = (uint32_t)g.tiles >> 3;
+        if (L < per * 8) L = (L & 7) * per + (L >> 3);
+    }
+    const uint32_t ct = fd_div(L, g.fdM);
+    const int m0 = (int)(L - ct * g.mtiles) * BM;
+    const int n0 = (int)ct * 128;
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    // ---- per-thread staging state ----
+    // FWD / DGRAD: A = NA4 x float4 along M, B = 16 gathered scalars of ONE column (rows b_k + 2q)
+    // WGRAD:       A = NAS, B = 16 scalars of ONE reduction index (tid & 31), rows/cols (tid >> 5) + 8q
+    // Global addresses are a wave-uniform 64-bit base (SGPRs, advanced on the scalar unit) plus a 32-bit per-lane byte
+    // offset; every tensor is < 2^32 bytes (mi_igemm_supported).
+    uint32_t a_lane = 0, b_lane = 0;
+    uint32_t mask = 0; // bit t: (class) tap t of this thread's column lies inside the image
+    int ph = 0, pw = 0, ntaps = 1;
+    int wg_t = 0, wg_r = 0, wg_s = 0, cblk = 0, kend = 0;
+    int ntiles = 0;
+    if (MODE == IG_FWD || MODE == IG_DGRAD) {
+        const int Mdim = MODE == IG_FWD ? g.K : g.C;
+        const int a_i = (tid & (BM / 4 - 1)) * 4, a_k = tid / (BM / 4);
+        a_lane = (uint32_t)(a_k * Mdim + a_i) * 4u;
+        const int j = n0 + (tid & 127);
+        const bool jin = j < g.ncols;
+        const uint32_t jc = jin ? (uint32_t)j : (uint32_t)g.ncols - 1;
+        const uint32_t n = fd_div(jc, g.fdP);
+        const uint32_t p = jc - n * g.P;
+        const uint32_t ho = fd_div(p, g.fdWo), wo = p - ho * g.Wo;
+        const int b_k = tid >> 7;
+        if (MODE == IG_FWD) {
+            // centre tap (S*ho, S*wo) is always inside the image
+            b_lane = (uint32_t)(n * g.C * g.HW + (S * ho) * g.W + S * wo + b_k * g.HW) * 4u;
+#pragma unroll
+            for (int t = 0; t < T; t++) {
+                const int hi = S * (int)ho - PAD + t / KS, wi = S * (int)wo - PAD + t % KS;
+                if (jin && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) mask |= 1u << t;
+            }
+            ntaps = T;
+            ntiles = T * (g.C / IG_BK);
+        } else if (S == 1) {
+            // one class, all taps: source pixel (h + PAD - r, w + PAD - s); (h, w) itself is the centre tap
+            b_lane = (uint32_t)(n * g.K * g.P + p + b_k * g.P) * 4u;
+#pragma unroll
+            for (int t = 0; t < T; t++) {
+                const int hs = (int)ho + PAD - t / KS, ws = (int)wo + PAD - t % KS;
+                if (jin && hs >= 0 && hs < g.Ho && ws >= 0 && ws < g.Wo) mask |= 1u << t;
+            }
+            ntaps = T;
+            ntiles = T * (g.K / IG_BK);
+        } else {
+            const int cls = 3 - (int)blockIdx.y; // heaviest class (4 taps) first
+            ph = cls >> 1; pw = cls & 1;
+            const int ntw = pw ? 2 : 1;
+            ntaps = (ph ? 2 : 1) * ntw;
+            b_lane = (uint32_t)(n * g.K * g.P + p + b_k * g.P) * 4u; // (a, b) itself is always a valid source pixel
+            for (int tt = 0; tt < ntaps; tt++) {
+                const int th = tt / ntw, tw = tt - th * ntw;
+                const int dh = (ph && th == 0) ? 1 : 0, dw = (pw && tw == 0) ? 1 : 0;
+                if (jin && (int)ho + dh < g.Ho && (int)wo + dw < g.Wo) mask |= 1u << tt;
+            }
+            ntiles = ntaps * (g.K / IG_BK);
+        }
+    } else {
+        wg_t = (int)(ct / (uint32_t)g.ctiles);
+        cblk = (int)(ct - (uint32_t)wg_t * g.ctiles) * 128;
+        wg_r = wg_t / KS; wg_s = wg_t - KS * wg_r;
+        const int kbeg = (int)blockIdx.y * g.klen;
+        kend = min(g.N * g.P, kbeg + g.klen);
+        ntiles = (kend - kbeg + IG_BK - 1) / IG_BK;
+    }
+
+    pf4 ra4[NA4];
+    float ra[NAS], rb[16];
+    int sel_a = 1, sel_b = 1;   // whether the values held in ra / rb are real (else they are stored to LDS as 0)
+    int ld_t = 0, ld_c0 = 0;    // next tile to fetch: tap (class tap) and first reduction channel
+    int ld_k0 = (MODE == IG_WGRAD) ? (int)blockIdx.y * g.klen : 0;
+    const char *fa = nullptr, *fb = nullptr; // wave-uniform bases of the tile being fetched (set by part 0)
+    uint32_t fa_lane = 0, fb_lane = 0;       // per-lane byte offsets of the tile being fetched
+    auto ldg = [](const char *ubase, uint32_t lane_off) -> float { return *(const float *)(ubase + lane_off); };
+    auto ldg4 = [](const char *ubase, uint32_t lane_off) -> pf4 { return *(const pf4 *)(ubase + lane_off); };
+
+    // Staging is cut into 8 parts so that it can be spread over the 16 MFMA groups of a tile.
+    auto fetch_part = [&](const int p) {
+        if (MODE == IG_FWD || MODE == IG_DGRAD) {
+            if (p == 0) {
+                // past the last tile (the two drain iterations fetch unconditionally) the last tap is simply read again
+                const int t = min(ld_t, ntaps - 1);
+                sel_b = (mask >> t) & 1;
+                if (MODE == IG_FWD) {
+                    const int r = KS == 3 ? (t * 11) >> 5 : 0, s = t - KS * r;
+                    fa = (const char *)(Aop + (size_t)(t * g.C + ld_c0) * g.K + m0);
+                    fb = (const char *)(Bop + (size_t)ld_c0 * g.HW);
+                    fb_lane = b_lane + (uint32_t)(sel_b * ((r - PAD) * g.W + (s - PAD)) * 4); // outside: centre pixel, stored as 0
+                    ld_c0 += IG_BK;
+                    if (ld_c0 == g.C) { ld_c0 = 0; ld_t++; }
+                } else {
+                    int wt, doff; // weight tap, source-pixel offset
+                    if (S == 1) {
+                        const int r = KS == 3 ? (t * 11) >> 5 : 0, s = t - KS * r;
+                        wt = t;
+                        doff = (PAD - r) * g.Wo + (PAD - s);
+                    } else {
+                        const int th = pw ? t >> 1 : t, tw = pw ? t & 1 : 0;
+                        const int r = ph ? 2 * th : 1, s = pw ? 2 * tw : 1;
+                        wt = 3 * r + s;
+                        doff = (ph & (th ^ 1)) * g.Wo + (pw & (tw ^ 1));
+                    }
+                    fa = (const char *)(Aop + (size_t)(wt * g.K + ld_c0) * g.C + m0);
+                    fb = (const char *)(Bop + (size_t)ld_c0 * g.P);
+                    fb_lane = b_lane + (uint32_t)(sel_b * doff * 4);
+                    ld_c0 += IG_BK;
+                    if (ld_c0 == g.K) { ld_c0 = 0; ld_t++; }
+                }
+            }
+            const size_t bstride = (MODE == IG_FWD ? (size_t)g.HW : (size_t)g.P) * 4;
+            const size_t astride = (MODE == IG_FWD ? (size_t)g.K : (size_t)g.C) * 4;
+            rb[2 * p] = ldg(fb + (size_t)(4 * p) * bstride, fb_lane);
+            rb[2 * p + 1] = ldg(fb + (size_t)(4 * p + 2) * bstride, fb_lane);
+            // A rows a_k + (32 / NA4) * q: spread over the parts
+            if (p % (8 / NA4) == 0) ra4[p / (8 / NA4)] = ldg4(fa + (size_t)(4 * p) * astride, a_lane);
+        } else {
+            if (p == 0) {
+                const int kk = ld_k0 + (tid & 31);
+                sel_a = kk < kend;
+                const uint32_t kc = sel_a ? (uint32_t)kk : (uint32_t)kend - 1;
+                const uint32_t n = fd_div_ge2(kc, g.fdP); // P, Wo >= 2 (mi_igemm_supported); no branches in here
+                const uint32_t pp = kc - n * g.P;
+                const uint32_t ho = fd_div_ge2(pp, g.fdWo), wo = pp - ho * g.Wo;
+                const int hi = S * (int)ho - PAD + wg_r, wi = S * (int)wo - PAD + wg_s;
+                const int inb = (int)((uint32_t)hi < (uint32_t)g.H) & (int)((uint32_t)wi < (uint32_t)g.W);
+                sel_b = sel_a & inb;
+                const uint32_t row = (uint32_t)tid >> 5;
+                fa = (const char *)(Aop + (size_t)m0 * g.P);
+                fb = (const char *)(Bop + (size_t)cblk * g.HW);
+                fa_lane = (n * (uint32_t)(g.K * g.P) + pp + row * g.P) * 4u;
+                const uint32_t pix = inb ? (uint32_t)(hi * g.W + wi) : (S * ho) * g.W + S * wo;
+                fb_lane = (n * (uint32_t)(g.C * g.HW) + pix + row * g.HW) * 4u;
+                ld_k0 += IG_BK;
+            }
+            if (NAS == 16) {
+                ra[2 * p] = ldg(fa + (size_t)(16 * p) * g.P * 4, fa_lane);
+                ra[2 * p + 1] = ldg(fa + (size_t)(16 * p + 8) * g.P * 4, fa_lane);
+            } else ra[p] = ldg(fa + (size_t)(8 * p) * g.P * 4, fa_lane);
+            rb[2 * p] = ldg(fb + (size_t)(16 * p) * g.HW * 4, fb_lane);
+            rb[2 * p + 1] = ldg(fb + (size_t)(16 * p + 8) * g.HW * 4, fb_lane);
+        }
+    };
+    auto stash_part = [&](const int buf, const int p) {
+        float *as = As + buf * IG_BK * LDA, *bs = Bs + buf * IG_BK * LDB;
+        if (MODE == IG_WGRAD) {
+            const int kx = tid & 31, row = tid >> 5;
+            if (NAS == 16) {
+                as[kx * LDA + row + 16 * p] = sel_a ? ra[2 * p] : 0.f;
+                as[kx * LDA + row + 16 * p + 8] = sel_a ? ra[2 * p + 1] : 0.f;
+            } else as[kx * LDA + row + 8 * p] = sel_a ? ra[p] : 0.f;
+            bs[kx * LDB + row + 16 * p] = sel_b ? rb[2 * p] : 0.f;
+            bs[kx * LDB + row + 16 * p + 8] = sel_b ? rb[2 * p + 1] : 0.f;
+        } else {
+            const int bj = tid & 127, b_k = tid >> 7;
+            bs[(b_k + 4 * p) * LDB + bj] = sel_b ? rb[2 * p] : 0.f;
+            bs[(b_k + 4 * p + 2) * LDB + bj] = sel_b ? rb[2 * p + 1] : 0.f;
+            if (p % (8 / NA4) == 0) {
+                const int a_i = (tid & (BM / 4 - 1)) * 4, a_k = tid / (BM / 4);
+                *(pf4 *)(as + (a_k + 4 * p) * LDA + a_i) = ra4[p / (8 / NA4)];
+            }
+        }
+    };
+
+    const int fr = lane & 31, fk = lane >> 5;
+#pragma unroll
+    for (int p = 0; p < 8; p++) fetch_part(p);
+#pragma unroll
+    for (int p = 0; p < 8; p++) stash_part(0, p);
+#pragma unroll
+    for (int p = 0; p < 8; p++) fetch_part(p);
+    // The loop is entered with NO load in flight: every register of tile 1 passes through an empty asm, so the compiler
+    // drains vmcnt here, once (header note 2).
+    if (MODE == IG_WGRAD) {
+#pragma unroll
+        for (int q = 0; q < NAS; q++) asm volatile("" : "+v"(ra[q]));
+    } else {
+#pragma unroll
+        for (int q = 0; q < NA4; q++) asm volatile("" : "+v"(ra4[q]));
+    }
+#pragma unroll
+    for (int q = 0; q < 16; q++) asm volatile("" : "+v"(rb[q]));
+    __syncthreads();
+    for (int it = 0; it < ntiles; it++) {
+        const int buf = it & 1;
+        // The registers hold tile it+1: it goes to the other buffer, then the registers are refilled with tile it+2.
+        constexpr bool st = IG_ABLATE != 1;
+        constexpr bool ft = IG_ABLATE != 1 && IG_ABLATE != 4;
+        const float *as = As + buf * IG_BK * LDA + fk * LDA + wm * 64 + fr;
+        const float *bs = Bs + buf * IG_BK * LDB + fk * LDB + wn * WNC + fr;
+        // fragments of step k2+2 are read while the MFMAs of step k2 run
+        float av[2][2], bv[2][TN];
+#pragma unroll
+        for (int i = 0; i < 2; i++) av[0][i] = as[i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; j++) bv[0][j] = bs[j * 32];
+#pragma unroll
+        for (int k2 = 0; k2 < IG_BK; k2 += 2) {
+            const int cur = (k2 >> 1) & 1, grp = k2 >> 1;
+            if (k2 + 2 < IG_BK) {
+#pragma unroll
+                for (int i = 0; i < 2; i++) av[cur ^ 1][i] = as[(k2 + 2) * LDA + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; j++) bv[cur ^ 1][j] = bs[(k2 + 2) * LDB + j * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0); // keep the reads ahead of the MFMAs (the scheduler would sink them to their use)
+            if (grp < 8) { if (st) stash_part(buf ^ 1, grp); }
+            else { if (ft) fetch_part(grp - 8); }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulator layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) ----
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int col = n0 + wn * WNC + j * 32 + (lane & 31);
+        size_t coff, rstride;
+        bool cok;
+        if (MODE == IG_WGRAD) {
+            cok = true;
+            coff = ((size_t)((size_t)blockIdx.y * T + wg_t) * g.K) * g.C + cblk + wn * WNC + j * 32 + (lane & 31);
+            rstride = (size_t)g.C;
+        } else {
+            cok = col < g.ncols;
+            const uint32_t jc = cok ? (uint32_t)col : 0u;
+            const uint32_t n = fd_div(jc, g.fdP);
+            const uint32_t p = jc - n * g.P;
+            if (MODE == IG_FWD) { coff = (size_t)n * g.K * g.P + p; rstride = (size_t)g.P; }
+            else if (S == 1) { coff = (size_t)n * g.C * g.HW + p; rstride = (size_t)g.HW; }
+            else {
+                const uint32_t a = fd_div(p, g.fdWo), b = p - a * g.Wo;
+                coff = (size_t)n * g.C * g.HW + (size_t)(2 * a + ph) * g.W + 2 * b + pw;
+                rstride = (size_t)g.HW;
+            }
+        }
+        if (!cok) continue;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            float ad[16];
+            if (MODE == IG_DGRAD && addend) {
+                // all 16 reads first: one latency, not sixteen
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    ad[r] = addend[coff + (size_t)(m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * rstride];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float v = acc[i][j][r];
+                if (MODE == IG_DGRAD && addend) v += ad[r];
+                Out[coff + (size_t)row * rstride] = v;
+            }
+        }
+    }
+}
+
+// weights KCRS -> [t][c][k] (forward A operand) or [t][k][c] (dgrad A operand); 32 x 32 (k, c) tiles through LDS
+template <int T>
+__global__ void __launch_bounds__(256)
+igemm_wt_kernel(const float *__restrict__ w, float *__restrict__ out, int K, int C, int to_tck) {
+    __shared__ float tile[32][T * 32 + 1];
+    const int k0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    // row k of the tile: 32 channels x T taps = contiguous floats of w
+    for (int e = threadIdx.x; e < 32 * T * 32; e += 256) {
+        const int kr = e / (T * 32), x = e - kr * (T * 32);
+        tile[kr][x] = w[((size_t)(k0 + kr) * C + c0) * T + x];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < T * 32 * 32; e += 256) {
+        const int t = e >> 10, u = (e >> 5) & 31, v = e & 31; // v fastest = contiguous output dim
+        if (to_tck) out[((size_t)t * C + c0 + u) * K + k0 + v] = tile[v][u * T + t];
+        else out[((size_t)t * K + k0 + u) * C + c0 + v] = tile[u][v * T + t];
+    }
+}
+
+// dW[k][c][t] = sum_z part[z][t][k][c] in ascending z (deterministic)
+template <int T>
+__global__ void __launch_bounds__(256)
+igemm_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, long KC, int splits) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= KC) return;
+    float s[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) s[t] = 0.f;
+    for (int z = 0; z < splits; z++)
+#pragma unroll
+        for (int t = 0; t < T; t++) s[t] += part[((long)z * T + t) * KC + i];
+#pragma unroll
+    for (int t = 0; t < T; t++) dw[i * T + t] = s[t];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+static int igemm_mode(void) {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("RESNET_MI_IGEMM"); on = e ? atoi(e) : 2; }
+    return on;
+}
+enum { IGOP_FWD = 0, IGOP_DGRAD = 1, IGOP_WGRAD = 2 };
+// Policy + shape gate.  RESNET_MI_IGEMM:
+//   0  off: every convolution on the older kernels (direct VALU 3x3/7x7, gemm_mfma_kernel 1x1)
+//   1  1x1 weight gradients and the 3x3/s2 projection shortcuts (K >= 2C) only: the bottleneck's own 3x3 convolutions
+//      stay on the direct VALU kernels
+//   2  (default) also every other 3x3 whose channel counts tile: measured on MI355X they are compute-bound, not
+//      HBM-bound (fp32 3x3 at C >= 64: >= 288 flop per byte), and the matrix cores run them at 90-119 TFLOP/s against
+//      60-75 on the vector ALUs
+// 1x1 forward and dgrad stay on gemm_mfma_kernel: with both operands contiguous its float4 staging issues half as many
+// VMEM instructions and the short reductions (C/32 = 2..64 k-steps) leave this kernel's deeper pipeline no room to pay.
+int mi_igemm_supported(int op, int N, int C, int H, int K, int k, int stride) {
+    const int mode = igemm_mode();
+    if (!mode) return 0;
+    if (!((k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2)))) return 0;
+    if (H % stride || H / stride < 2) return 0;
+    if (k == 1 && op != IGOP_WGRAD) return 0;
+    if (k == 3 && mode == 1 && !(stride == 2 && K >= 2 * C && C >= 256)) return 0; // projections only
+    if ((double)N * C * H * H >= 1073741824.0 || (double)N * K * (H / stride) * (H / stride) >= 1073741824.0) return 0; /* 32-bit byte offsets */
+    if (op == IGOP_FWD) return C % 32 == 0 && K % 64 == 0;
+    if (op == IGOP_DGRAD) return K % 32 == 0 && C % 64 == 0;
+    return C % 128 == 0 && K % 64 == 0;
+}
+static int igemm_wgrad_splits(int N, int C, int H, int K, int k, int stride) {
+    const int bm = K % 128 == 0 ? 128 : 64;
+    const long tiles = (long)k * k * (C / 128) * (K / bm);
+    const long ksteps = ((long)N * (H / stride) * (H / stride) + IG_BK - 1) / IG_BK;
+    const long slots = 512; // 256 CUs x 2 resident workgroups
+    int best = 1;
+    double best_eff = 0;
+    for (int s = 1; s <= 512; s++) {
+        if (s > 1 && ksteps / s < 48) break;
+        const double waves = (double)tiles * s / slots;
+        const double eff = waves / (double)((long)((tiles * s + slots - 1) / slots));
+        if (eff > best_eff + 0.02) { best_eff = eff; best = s; }
+    }
+    return best;
+}
+size_t mi_igemm_part_floats(int N, int C, int H, int K, int k, int stride) {
+    return (size_t)igemm_wgrad_splits(N, C, H, K, k, stride) * k * k * K * C;
+}
+
+static void igemm_geometry(IgArgs &g, int N, int C, int H, int K, int stride) {
+    g.N = N; g.C = C; g.K = K; g.H = H; g.W = H; g.Ho = H / stride; g.Wo = H / stride;
+    g.HW = H * H; g.P = g.Ho * g.Wo;
+    g.ncols = N * g.P;
+    g.fdP = make_fastdiv(g.P); g.fdWo = make_fastdiv(g.Wo);
+}
+template <int MODE, int KS, int S, int WMW>
+static int igemm_launch_t(hipStream_t st, dim3 grid, const float *A, const float *B, float *out, const float *addend, const IgArgs &g) {
+    constexpr int BM = 64 * WMW;
+    constexpr int LDA = (MODE == IG_WGRAD) ? BM + 1 : BM + 4, LDB = (MODE == IG_WGRAD) ? 129 : 132;
+    constexpr size_t lds = (size_t)2 * IG_BK * (LDA + LDB) * sizeof(float);
+    static int attr_set = 0;
+    if (!attr_set) {
+        if (lds > 64 * 1024 &&
+            hipFuncSetAttribute((const void *)igemm_kernel<MODE, KS, S, WMW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            mi_record_error("igemm_kernel", "cannot raise the dynamic LDS limit");
+            return -1;
+        }
+        attr_set = 1;
+    }
+    hipLaunchKernelGGL((igemm_kernel<MODE, KS, S, WMW>), grid, dim3(256), lds, st, A, B, out, addend, g);
+    return 0;
+}
+template <int MODE>
+static int igemm_launch(hipStream_t st, dim3 grid, const float *A, const float *B, float *out, const float *addend, const IgArgs &g,
+                        int k, int stride, int bm) {
+#define IGL(KS_, S_)                                                                                      \
+    if (k == KS_ && stride == S_)                                                                         \
+        return bm == 128 ? igemm_launch_t<MODE, KS_, S_, 2>(st, grid, A, B, out, addend, g)               \
+                         : igemm_launch_t<MODE, KS_, S_, 1>(st, grid, A, B, out, addend, g);
+    IGL(1, 1) IGL(3, 1) IGL(3, 2)
+#undef IGL
+    return -2;
+}
+static int igemm_fam(int k) { return k == 1 ? MI_FAM_GEMM : MI_FAM_PCONV; }
+
+int mi_igemm_fwd(hipStream_t st, mid_workspace *ws, const float *x, const float *w, float *y, int N, int C, int H, int K, int k,
+                 int stride) {
+    const int T = k * k;
+    if (!ws || ws->wt_floats < (size_t)T * C * K) { mi_record_error("mi_igemm_fwd", "workspace too small"); return -3; }
+    if (k == 1) hipLaunchKernelGGL(igemm_wt_kernel<1>, dim3(C / 32, K / 32), dim3(256), 0, st, w, ws->wt, K, C, 1);
+    else hipLaunchKernelGGL(igemm_wt_kernel<9>, dim3(C / 32, K / 32), dim3(256), 0, st, w, ws->wt, K, C, 1);
+    MI_LAUNCH_CHECK("igemm_wt_kernel");
+    IgArgs g = {};
+    igemm_geometry(g, N, C, H, K, stride);
+    const int bm = K % 128 == 0 ? 128 : 64;
+    g.mtiles = K / bm;
+    g.tiles = g.mtiles * mi_cdiv(g.ncols, 128);
+    g.fdM = make_fastdiv(g.mtiles);
+    mi_prof_begin(st, igemm_fam(k), 2.0 * T * (double)g.ncols * C * K,
+                  4.0 * ((double)N * C * g.HW + (double)T * C * K + (double)g.ncols * K));
+    const int rc = igemm_launch<IG_FWD>(st, dim3(g.tiles), ws->wt, x, y, nullptr, g, k, stride, bm);
+    mi_prof_end(st);
+    if (rc) return rc;
+    MI_LAUNCH_CHECK("igemm_kernel<fwd>");
+    return 0;
+}
+
+int mi_igemm_dgrad(hipStream_t st, mid_workspace *ws, const float *w, const float *dy, float *dx, const float *addend, int N,
+                   int C, int H, int K, int k, int stride) {
+    const int T = k * k;
+    const float *A = w; // 1x1: the KC tensor is already [k][c]
+    if (k == 3) {
+        if (!ws || ws->wt_floats < (size_t)T * C * K) { mi_record_error("mi_igemm_dgrad", "workspace too small"); return -3; }
+        hipLaunchKernelGGL(igemm_wt_kernel<9>, dim3(C / 32, K / 32), dim3(256), 0, st, w, ws->wt, K, C, 0);
+        MI_LAUNCH_CHECK("igemm_wt_kernel");
+        A = ws->wt;
+    }
+    IgArgs g = {};
+    igemm_geometry(g, N, C, H, K, stride);
+    const int bm = C % 128 == 0 ? 128 : 64;
+    g.mtiles = C / bm;
+    g.tiles = g.mtiles * mi_cdiv(g.ncols, 128);
+    g.fdM = make_fastdiv(g.mtiles);
+    mi_prof_begin(st, igemm_fam(k), 2.0 * T * (double)g.ncols * C * K,
+                  4.0 * ((double)g.ncols * K + (double)T * C * K + (double)N * C * g.HW * (addend ? 2 : 1)));
+    const int rc = igemm_launch<IG_DGRAD>(st, dim3(g.tiles, stride == 2 ? 4 : 1), A, dy, dx, addend, g, k, stride, bm);
+    mi_prof_end(st);
+    if (rc) return rc;
+    MI_LAUNCH_CHECK("igemm_kernel<dgrad>");
+    return 0;
+}
+
+int mi_igemm_wgrad(hipStream_t st, mid_workspace *ws, const float *x, const float *dy, float *dw, int N, int C, int H, int K, int k,
+                   int stride) {
+    const int T = k * k;
+    const int splits = igemm_wgrad_splits(N, C, H, K, k, stride);
+    if (!ws || ws->part_floats < (size_t)splits * T * K * C) { mi_record_error("mi_igemm_wgrad", "workspace too small"); return -3; }
+    IgArgs g = {};
+    igemm_geometry(g, N, C, H, K, stride);
+    const int bm = K % 128 == 0 ? 128 : 64;
+    g.mtiles = K / bm;
+    g.ctiles = C / 128;
+    g.tiles = g.mtiles * T * g.ctiles;
+    g.fdM = make_fastdiv(g.mtiles);
+    const int kd = N * g.P;
+    g.klen = mi_cdiv(mi_cdiv(kd, splits), IG_BK) * IG_BK;
+    const int used = mi_cdiv(kd, g.klen);
+    mi_prof_begin(st, igemm_fam(k), 2.0 * T * (double)kd * C * K,
+                  4.0 * ((double)N * C * g.HW + (double)kd * K + (double)T * C * K));
+    const int rc = igemm_launch<IG_WGRAD>(st, dim3(g.tiles, used), dy, x, ws->part, nullptr, g, k, stride, bm);
+    mi_prof_end(st);
+    if (rc) return rc;
+    MI_LAUNCH_CHECK("igemm_kernel<wgrad>");
+    const long KC = (long)K * C;
+    if (k == 1) hipLaunchKernelGGL(igemm_wgrad_reduce_kernel<1>, dim3(mi_cdiv(KC, 256)), dim3(256), 0, st, ws->part, dw, KC, used);
+    else hipLaunchKernelGGL(igemm_wgrad_reduce_kernel<9>, dim3(mi_cdiv(KC, 256)), dim3(256), 0, st, ws->part, dw, KC, used);
+    MI_LAUNCH_CHECK("igemm_wgrad_reduce_kernel");
+    return 0;
+}
