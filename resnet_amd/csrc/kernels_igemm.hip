@@ -97,7 +97,8 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
     // ---- per-thread staging state ----
-    // FWD / DGRAD: A = NA4 x float4 along M, B = 16 gathered scalars of ONE column (rows b_k + 2q)
+    // FWD / DGRAD: A = NA4 x float4 along M, B = 16 gathered scalars of ONE column (rows 16*b_k + q: neighbouring rows
+    //              pair up into ds_write2_b32)
     // WGRAD:       A = NAS, B = 16 scalars of ONE reduction index (tid & 31), rows/cols (tid >> 5) + 8q
     // Global addresses are a wave-uniform 64-bit base (SGPRs, advanced on the scalar unit) plus a 32-bit per-lane byte
     // offset; every tensor is < 2^32 bytes (mi_igemm_supported).
@@ -119,7 +120,7 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
         const int b_k = tid >> 7;
         if (MODE == IG_FWD) {
             // centre tap (S*ho, S*wo) is always inside the image
-            b_lane = (uint32_t)(n * g.C * g.HW + (S * ho) * g.W + S * wo + b_k * g.HW) * 4u;
+            b_lane = (uint32_t)(n * g.C * g.HW + (S * ho) * g.W + S * wo + 16 * b_k * g.HW) * 4u;
 #pragma unroll
             for (int t = 0; t < T; t++) {
                 const int hi = S * (int)ho - PAD + t / KS, wi = S * (int)wo - PAD + t % KS;
@@ -129,7 +130,7 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
             ntiles = T * (g.C / IG_BK);
         } else if (S == 1) {
             // one class, all taps: source pixel (h + PAD - r, w + PAD - s); (h, w) itself is the centre tap
-            b_lane = (uint32_t)(n * g.K * g.P + p + b_k * g.P) * 4u;
+            b_lane = (uint32_t)(n * g.K * g.P + p + 16 * b_k * g.P) * 4u;
 #pragma unroll
             for (int t = 0; t < T; t++) {
                 const int hs = (int)ho + PAD - t / KS, ws = (int)wo + PAD - t % KS;
@@ -142,7 +143,7 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
             ph = cls >> 1; pw = cls & 1;
             const int ntw = pw ? 2 : 1;
             ntaps = (ph ? 2 : 1) * ntw;
-            b_lane = (uint32_t)(n * g.K * g.P + p + b_k * g.P) * 4u; // (a, b) itself is always a valid source pixel
+            b_lane = (uint32_t)(n * g.K * g.P + p + 16 * b_k * g.P) * 4u; // (a, b) itself is always a valid source pixel
             for (int tt = 0; tt < ntaps; tt++) {
                 const int th = tt / ntw, tw = tt - th * ntw;
                 const int dh = (ph && th == 0) ? 1 : 0, dw = (pw && tw == 0) ? 1 : 0;
@@ -204,8 +205,8 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
             }
             const size_t bstride = (MODE == IG_FWD ? (size_t)g.HW : (size_t)g.P) * 4;
             const size_t astride = (MODE == IG_FWD ? (size_t)g.K : (size_t)g.C) * 4;
-            rb[2 * p] = ldg(fb + (size_t)(4 * p) * bstride, fb_lane);
-            rb[2 * p + 1] = ldg(fb + (size_t)(4 * p + 2) * bstride, fb_lane);
+            rb[2 * p] = ldg(fb + (size_t)(2 * p) * bstride, fb_lane);
+            rb[2 * p + 1] = ldg(fb + (size_t)(2 * p + 1) * bstride, fb_lane);
             // A rows a_k + (32 / NA4) * q: spread over the parts
             if (p % (8 / NA4) == 0) ra4[p / (8 / NA4)] = ldg4(fa + (size_t)(4 * p) * astride, a_lane);
         } else {
@@ -247,8 +248,8 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
             bs[kx * LDB + row + 16 * p + 8] = sel_b ? rb[2 * p + 1] : 0.f;
         } else {
             const int bj = tid & 127, b_k = tid >> 7;
-            bs[(b_k + 4 * p) * LDB + bj] = sel_b ? rb[2 * p] : 0.f;
-            bs[(b_k + 4 * p + 2) * LDB + bj] = sel_b ? rb[2 * p + 1] : 0.f;
+            bs[(16 * b_k + 2 * p) * LDB + bj] = sel_b ? rb[2 * p] : 0.f;
+            bs[(16 * b_k + 2 * p + 1) * LDB + bj] = sel_b ? rb[2 * p + 1] : 0.f;
             if (p % (8 / NA4) == 0) {
                 const int a_i = (tid & (BM / 4 - 1)) * 4, a_k = tid / (BM / 4);
                 *(pf4 *)(as + (a_k + 4 * p) * LDA + a_i) = ra4[p / (8 / NA4)];

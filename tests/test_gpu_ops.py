@@ -214,3 +214,23 @@ def test_softmax_ce_adam(ops, oracle):
 def test_layout(ops):
     x = rand((3, 10, 10, 7), 71)
     assert np.array_equal(ops.nhwc_to_nchw(x), nchw(x))
+
+
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_conv_parity_on_the_other_kernel_routes(mode):
+    """RESNET_MI_IGEMM selects which kernels a convolution runs on (kernels_igemm.hip: mi_igemm_supported).  The default
+    (2) sends every tiling 3x3 and the 1x1 weight gradients to the MFMA implicit GEMM; 1 keeps the bottleneck's own 3x3
+    convolutions on the direct VALU kernels (only the projection shortcuts and 1x1 wgrad on MFMA); 0 uses the direct
+    kernels and gemm_mfma_kernel for everything.  The routes are read once per process, so the conv parity tests of
+    this file are re-run in a child process per route: every kernel family stays pinned to the oracle at the
+    ResNet-50 layer shapes whichever route is the default."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, RESNET_MI_IGEMM=mode)
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_ops.py"), "-x", "-q", "-m", "gpu",
+                        "-k", "test_conv_fwd or test_conv_dgrad or test_conv_wgrad or unwritten_lds", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(here))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
