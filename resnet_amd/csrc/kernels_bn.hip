@@ -48,22 +48,59 @@ __device__ __forceinline__ void wel_add1(Wel &w, float a) {
     w = wel_merge(w, t);
 }
 
-// grid (C, nsplit): block handles channel c, images n = split, split+nsplit, ...
+// Merge a batch of NB values (already summed: bs = sum, and centred squares bm2 about its own mean bmean) into w.
+__device__ __forceinline__ void wel_add_batch(Wel &w, float nb, float bmean, float bm2) {
+    Wel t; t.n = nb; t.mean = bmean; t.m2 = bm2;
+    w = wel_merge(w, t);
+}
+
+// grid (C, nsplit): block handles channel c, images n = split, split+nsplit, ...  The (image, position) pairs of the
+// block are ONE flattened index space walked by all 256 threads with four 16-byte loads in flight per thread: a 14x14 or
+// 7x7 plane (49 float4 / 49 floats) no longer leaves 80% of the lanes idle, and a thread merges once per 16 values.
+template <bool VEC>
 __global__ void __launch_bounds__(256)
-bn_stats_kernel(const float *__restrict__ x, float *__restrict__ partial, int N, int C, int P) {
+bn_stats_kernel(const float *__restrict__ x, float *__restrict__ partial, int N, int C, int P, FastDiv fdPV) {
     const int c = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+    const int cnt = (N - split + nsplit - 1) / nsplit;            // images of this block
+    constexpr int V = VEC ? 4 : 1;
+    const uint32_t PV = (uint32_t)P / V;                          // units per plane
+    const uint32_t total = (uint32_t)cnt * PV;
+    const size_t img_stride = (size_t)nsplit * C * P;
+    const float *base = x + ((size_t)split * C + c) * P;
     Wel w = {0.f, 0.f, 0.f};
-    if ((P & 3) == 0) {
-        const int P4 = P >> 2;
-        for (int n = split; n < N; n += nsplit) {
-            const float4 *src = (const float4 *)(x + ((size_t)n * C + c) * P);
-            for (int i = threadIdx.x; i < P4; i += blockDim.x) { const float4 v = src[i]; wel_add4(w, v.x, v.y, v.z, v.w); }
+    auto addr = [&](uint32_t idx) -> const float * {
+        const uint32_t j = fd_div(idx, fdPV), i = idx - j * PV;
+        return base + (size_t)j * img_stride + (size_t)i * V;
+    };
+    uint32_t idx = threadIdx.x;
+    for (; idx + 3 * 256 < total; idx += 4 * 256) {
+        if (VEC) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = *(const float4 *)addr(idx + u * 256);
+            float s = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; u++) s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+            const float bm = s * (1.0f / 16.0f);
+            float m2 = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float a = v[u].x - bm, b = v[u].y - bm, cc = v[u].z - bm, d = v[u].w - bm;
+                m2 += (a * a + b * b) + (cc * cc + d * d);
+            }
+            wel_add_batch(w, 16.f, bm, m2);
+        } else {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = *addr(idx + u * 256);
+            const float bm = ((v[0] + v[1]) + (v[2] + v[3])) * 0.25f;
+            const float a = v[0] - bm, b = v[1] - bm, cc = v[2] - bm, d = v[3] - bm;
+            wel_add_batch(w, 4.f, bm, (a * a + b * b) + (cc * cc + d * d));
         }
-    } else {
-        for (int n = split; n < N; n += nsplit) {
-            const float *src = x + ((size_t)n * C + c) * P;
-            for (int i = threadIdx.x; i < P; i += blockDim.x) wel_add1(w, src[i]);
-        }
+    }
+    for (; idx < total; idx += 256) {
+        if (VEC) { const float4 v = *(const float4 *)addr(idx); wel_add4(w, v.x, v.y, v.z, v.w); }
+        else wel_add1(w, *addr(idx));
     }
     w = wel_wave(w);
     __shared__ Wel sh[4];
@@ -136,14 +173,20 @@ bn_apply_kernel(const float *__restrict__ x, const float *__restrict__ gamma, co
     }
 }
 
-// grid (C, nsplit): s1 = sum g, s2 = sum g * x_hat
-template <int MASK>
+// grid (C, nsplit): s1 = sum g, s2 = sum g * x_hat.  Same flattened (image, position) walk as bn_stats_kernel.
+template <int MASK, bool VEC>
 __global__ void __launch_bounds__(256)
 bn_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ mask_src,
                      const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ means,
-                     const float *__restrict__ vars, float *__restrict__ partial, int N, int C, int P, float eps) {
+                     const float *__restrict__ vars, float *__restrict__ partial, int N, int C, int P, float eps, FastDiv fdPV) {
     const int c = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
     const float mean = means[c], sd = sqrtf(vars[c] + eps), g = gamma[c], b = beta[c];
+    const int cnt = (N - split + nsplit - 1) / nsplit;
+    constexpr int V = VEC ? 4 : 1;
+    const uint32_t PV = (uint32_t)P / V;
+    const uint32_t total = (uint32_t)cnt * PV;
+    const size_t img_stride = (size_t)nsplit * C * P;
+    const size_t base = ((size_t)split * C + c) * P;
     float s1 = 0.f, s2 = 0.f;
     auto one = [&](float xv, float d, float m) {
         const float xh = bn_xhat(xv, mean, sd);
@@ -152,25 +195,45 @@ bn_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ dy, 
         if (MASK == 2) on = m > 0.f;
         if (on) { s1 += d; s2 = fmaf(d, xh, s2); }
     };
-    if ((P & 3) == 0) {
-        const int P4 = P >> 2;
-        for (int n = split; n < N; n += nsplit) {
-            const size_t base = ((size_t)n * C + c) * P;
-            const float4 *xs = (const float4 *)(x + base), *ds = (const float4 *)(dy + base);
-            const float4 *ms = (const float4 *)(mask_src + (MASK == 2 ? base : 0));
-            for (int i = threadIdx.x; i < P4; i += blockDim.x) {
-                const float4 xv = xs[i], dv = ds[i];
-                float4 mv = make_float4(1.f, 1.f, 1.f, 1.f);
-                if (MASK == 2) mv = ms[i];
-                one(xv.x, dv.x, mv.x); one(xv.y, dv.y, mv.y); one(xv.z, dv.z, mv.z); one(xv.w, dv.w, mv.w);
+    auto off = [&](uint32_t idx) -> size_t {
+        const uint32_t j = fd_div(idx, fdPV), i = idx - j * PV;
+        return base + (size_t)j * img_stride + (size_t)i * V;
+    };
+    constexpr int U = MASK == 2 ? 2 : 4; // loads in flight per thread: U x (2 or 3) x 16 B
+    uint32_t idx = threadIdx.x;
+    for (; idx + (U - 1) * 256 < total; idx += U * 256) {
+        if (VEC) {
+            float4 xv[U], dv[U], mv[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const size_t o = off(idx + u * 256);
+                xv[u] = *(const float4 *)(x + o); dv[u] = *(const float4 *)(dy + o);
+                if (MASK == 2) mv[u] = *(const float4 *)(mask_src + o); else mv[u] = make_float4(1.f, 1.f, 1.f, 1.f);
             }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                one(xv[u].x, dv[u].x, mv[u].x); one(xv[u].y, dv[u].y, mv[u].y);
+                one(xv[u].z, dv[u].z, mv[u].z); one(xv[u].w, dv[u].w, mv[u].w);
+            }
+        } else {
+            float xv[U], dv[U], mv[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const size_t o = off(idx + u * 256);
+                xv[u] = x[o]; dv[u] = dy[o]; mv[u] = MASK == 2 ? mask_src[o] : 1.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) one(xv[u], dv[u], mv[u]);
         }
-    } else {
-        for (int n = split; n < N; n += nsplit) {
-            const size_t base = ((size_t)n * C + c) * P;
-            for (int i = threadIdx.x; i < P; i += blockDim.x)
-                one(x[base + i], dy[base + i], MASK == 2 ? mask_src[base + i] : 1.f);
-        }
+    }
+    for (; idx < total; idx += 256) {
+        const size_t o = off(idx);
+        if (VEC) {
+            const float4 xv = *(const float4 *)(x + o), dv = *(const float4 *)(dy + o);
+            float4 mv = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (MASK == 2) mv = *(const float4 *)(mask_src + o);
+            one(xv.x, dv.x, mv.x); one(xv.y, dv.y, mv.y); one(xv.z, dv.z, mv.z); one(xv.w, dv.w, mv.w);
+        } else one(x[o], dy[o], MASK == 2 ? mask_src[o] : 1.f);
     }
     s1 = wave_sum(s1); s2 = wave_sum(s2);
     __shared__ float sh[8];
@@ -256,7 +319,8 @@ int mid_bn_fwd(mid_stream s, float *ws, const float *x, const float *gamma, cons
     hipStream_t st = (hipStream_t)s;
     const int ns = bn_nsplit(N, C);
     mi_prof_begin(st, MI_FAM_BN, 0.0, 4.0 * (double)N * C * P * (residual ? 4 : 3));
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, ns), dim3(256), 0, st, x, ws, N, C, P);
+    if ((P & 3) == 0) hipLaunchKernelGGL((bn_stats_kernel<true>), dim3(C, ns), dim3(256), 0, st, x, ws, N, C, P, make_fastdiv(P / 4));
+    else hipLaunchKernelGGL((bn_stats_kernel<false>), dim3(C, ns), dim3(256), 0, st, x, ws, N, C, P, make_fastdiv(P));
     MI_LAUNCH_CHECK("bn_stats_kernel");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(mi_cdiv(C, 64)), dim3(64), 0, st, ws, ns, C, means, vars);
     MI_LAUNCH_CHECK("bn_finalize_kernel");
@@ -281,9 +345,13 @@ int mid_bn_bwd(mid_stream s, float *ws, const float *x, const float *gamma, cons
     dim3 grid(C, ns), block(256);
     if (mask_mode == 2 && !mask_src) { mi_record_error("mid_bn_bwd", "mask_src missing"); return -2; }
     mi_prof_begin(st, MI_FAM_BN, 0.0, 4.0 * (double)N * C * P * (mask_mode == 2 ? 7 : 5));
-    if (mask_mode == 0) hipLaunchKernelGGL((bn_bwd_reduce_kernel<0>), grid, block, 0, st, x, dy, mask_src, gamma, beta, means, vars, ws, N, C, P, eps);
-    else if (mask_mode == 1) hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), grid, block, 0, st, x, dy, mask_src, gamma, beta, means, vars, ws, N, C, P, eps);
-    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<2>), grid, block, 0, st, x, dy, mask_src, gamma, beta, means, vars, ws, N, C, P, eps);
+    const bool rvec = (P & 3) == 0;
+    const FastDiv fdPV = make_fastdiv(rvec ? P / 4 : P);
+#define BWD_REDUCE(M_, V_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<M_, V_>), grid, block, 0, st, x, dy, mask_src, gamma, beta, means, vars, ws, N, C, P, eps, fdPV)
+    if (mask_mode == 0) { if (rvec) BWD_REDUCE(0, true); else BWD_REDUCE(0, false); }
+    else if (mask_mode == 1) { if (rvec) BWD_REDUCE(1, true); else BWD_REDUCE(1, false); }
+    else { if (rvec) BWD_REDUCE(2, true); else BWD_REDUCE(2, false); }
+#undef BWD_REDUCE
     MI_LAUNCH_CHECK("bn_bwd_reduce_kernel");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(mi_cdiv(C, 64)), dim3(64), 0, st, ws, ns, C, dgamma, dbeta);
     MI_LAUNCH_CHECK("bn_bwd_finalize_kernel");
