@@ -659,6 +659,7 @@ size_t mi_conv1x1_wgrad_part_floats(int N, int C, int P, int K);
 enum { IGOP_FWD = 0, IGOP_DGRAD = 1, IGOP_WGRAD = 2 };
 int mi_igemm_supported(int op, int N, int C, int H, int K, int k, int stride);
 size_t mi_igemm_part_floats(int N, int C, int H, int K, int k, int stride);
+size_t mi_igemm_tail_floats(void);
 int mi_igemm_fwd(hipStream_t st, mid_workspace *ws, const float *x, const float *w, float *y, int N, int C, int H, int K, int k,
                  int stride);
 int mi_igemm_dgrad(hipStream_t st, mid_workspace *ws, const float *w, const float *dy, float *dx, const float *addend, int N,
@@ -668,7 +669,8 @@ int mi_igemm_wgrad(hipStream_t st, mid_workspace *ws, const float *x, const floa
 
 extern "C" {
 
-size_t mid_conv_ws_wt_floats(int C, int K, int k) { return (size_t)k * k * C * K; } /* 1x1 forward re-lays W to [c][k] too */
+/* re-laid weights, followed by the partial tiles of igemm's reduction-sliced tail workgroups (compute stream only) */
+size_t mid_conv_ws_wt_floats(int C, int K, int k) { return (size_t)k * k * C * K + (k == 3 ? mi_igemm_tail_floats() : 0); }
 
 size_t mid_conv_ws_part_floats(int N, int C, int H, int K, int k, int stride) {
     if (mi_igemm_supported(IGOP_WGRAD, N, C, H, K, k, stride)) return mi_igemm_part_floats(N, C, H, K, k, stride);

@@ -52,6 +52,11 @@ struct IgArgs {
     int ctiles;                // wgrad: C/128
     int klen;                  // wgrad: reduction length per split (multiple of 32)
     FastDiv fdP, fdWo, fdM;    // fdM: division by mtiles
+    // fwd / dgrad-s1 tail slicing (igemm_tail_plan): tiles >= full are cut into tsplit reduction slices of tklen k-steps
+    // whose partial tiles go to tailbuf and are summed in slice order by igemm_tail_reduce_kernel
+    int full, tsplit, tklen, cpt; // cpt: k-steps per tap
+    FastDiv fdTs, fdCpt;
+    float *tailbuf;
 };
 
 #define IG_BK 32
@@ -78,10 +83,19 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = WMW == 2 ? wave >> 1 : 0, wn = WMW == 2 ? wave & 1 : wave;
 
-    // ---- block -> tile (XCD-contiguous, M-tiles fastest) ----
+    // ---- block -> tile (XCD-contiguous, M-tiles fastest); blocks past g.full are reduction slices of the last tiles ----
     uint32_t L = blockIdx.x;
-    {
-        const uint32_t per = (uint32_t)g.tiles >> 3;
+    int tail_id = -1, it0 = 0, nt_slice = 0;
+    if (MODE != IG_WGRAD && g.tsplit > 1 && L >= (uint32_t)g.full) {
+        tail_id = (int)(L - (uint32_t)g.full);
+        const uint32_t tl = fd_div((uint32_t)tail_id, g.fdTs);
+        const int z = tail_id - (int)tl * g.tsplit;
+        L = (uint32_t)g.full + tl;
+        it0 = z * g.tklen;
+        nt_slice = g.tklen;
+    } else {
+        const uint32_t lim = MODE != IG_WGRAD && g.tsplit > 1 ? (uint32_t)g.full : (uint32_t)g.tiles;
+        const uint32_t per = lim >> 3;
         if (L < per * 8) L = (L & 7) * per + (L >> 3);
     }
     const uint32_t ct = fd_div(L, g.fdM);
@@ -164,6 +178,11 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
     float ra[NAS], rb[16];
     int sel_a = 1, sel_b = 1;   // whether the values held in ra / rb are real (else they are stored to LDS as 0)
     int ld_t = 0, ld_c0 = 0;    // next tile to fetch: tap (class tap) and first reduction channel
+    if (MODE != IG_WGRAD && tail_id >= 0) { // a reduction slice: k-steps [it0, it0 + nt_slice) of the tile
+        ld_t = (int)fd_div((uint32_t)it0, g.fdCpt);
+        ld_c0 = (it0 - ld_t * g.cpt) * IG_BK;
+        ntiles = min(nt_slice, ntiles - it0);
+    }
     int ld_k0 = (MODE == IG_WGRAD) ? (int)blockIdx.y * g.klen : 0;
     const char *fa = nullptr, *fb = nullptr; // wave-uniform bases of the tile being fetched (set by part 0)
     uint32_t fa_lane = 0, fb_lane = 0;       // per-lane byte offsets of the tile being fetched
@@ -312,6 +331,17 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
     }
 
     // ---- epilogue: accumulator layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) ----
+    if (MODE != IG_WGRAD && tail_id >= 0) {
+        float *tb = g.tailbuf + (size_t)tail_id * (BM * 128);
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    tb[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 128 + wn * WNC + j * 32 + (lane & 31)] = acc[i][j][r];
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; j++) {
         const int col = n0 + wn * WNC + j * 32 + (lane & 31);
@@ -352,6 +382,31 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
                 Out[coff + (size_t)row * rstride] = v;
             }
         }
+    }
+}
+
+// Sum of the reduction slices of the tail tiles, in slice order (deterministic), written where the tile's own epilogue
+// would have put it.  grid = number of tail tiles; thread = one column, BM/2 rows.
+template <int MODE, int BM>
+__global__ void __launch_bounds__(256)
+igemm_tail_reduce_kernel(float *__restrict__ Out, const float *__restrict__ addend, const IgArgs g) {
+    const uint32_t L = (uint32_t)g.full + blockIdx.x;
+    const uint32_t ct = fd_div(L, g.fdM);
+    const int m0 = (int)(L - ct * g.mtiles) * BM;
+    const int col = (int)ct * 128 + (threadIdx.x & 127);
+    if (col >= g.ncols) return;
+    const uint32_t n = fd_div((uint32_t)col, g.fdP);
+    const uint32_t p = (uint32_t)col - n * g.P;
+    size_t coff, rstride;
+    if (MODE == IG_FWD) { coff = (size_t)n * g.K * g.P + p; rstride = (size_t)g.P; }
+    else { coff = (size_t)n * g.C * g.HW + p; rstride = (size_t)g.HW; }
+    const float *tb = g.tailbuf + (size_t)blockIdx.x * g.tsplit * (BM * 128) + (threadIdx.x & 127);
+    for (int row = threadIdx.x >> 7; row < BM; row += 2) {
+        float v = 0.f;
+        for (int z = 0; z < g.tsplit; z++) v += tb[(size_t)z * (BM * 128) + row * 128];
+        const size_t o = coff + (size_t)(m0 + row) * rstride;
+        if (MODE == IG_DGRAD && addend) v += addend[o];
+        Out[o] = v;
     }
 }
 
@@ -437,6 +492,34 @@ size_t mi_igemm_part_floats(int N, int C, int H, int K, int k, int stride) {
     return (size_t)igemm_wgrad_splits(N, C, H, K, k, stride) * k * k * K * C;
 }
 
+#define IG_SLOTS 512              /* 256 CUs x 2 resident workgroups */
+#define IG_TAIL_FLOATS ((size_t)IG_SLOTS * 128 * 128) /* partial-tile buffer: one slice per slot, 33.5 MB */
+size_t mi_igemm_tail_floats(void) { return igemm_mode() ? IG_TAIL_FLOATS : 0; }
+// Workgroup-count quantisation: `tiles` equal workgroups on IG_SLOTS resident slots run in ceil(tiles / IG_SLOTS) rounds, so
+// a last round that fills only a fraction of the chip costs a whole round (ResNet-50 at N=256: the 1024->2048 @14
+// projection has 1568 tiles = 3.06 rounds).  The `rem` tiles of that last round are cut into s = IG_SLOTS / rem slices along
+// the reduction, each slice a workgroup of its own: the round shrinks to 1/s of its length (b13 projection forward
+// 104.9 -> 111.3 TFLOP/s).  Measured and rejected: slicing a last round that is more than half full into more than
+// IG_SLOTS slices (several short rounds) -- the partial-tile traffic and the second-stage launch cost more than the
+// idle slots did (256@14 forward 0.63 -> 0.71 ms).
+static void igemm_tail_plan(IgArgs &g, int ksteps, float *tailbuf) {
+    g.full = g.tiles; g.tsplit = 1; g.tklen = ksteps; g.tailbuf = tailbuf;
+    g.fdTs = make_fastdiv(1);
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("RESNET_MI_IGEMM_TAIL"); on = e ? atoi(e) : 1; }
+    if (!on || !tailbuf) return;
+    const int rem = g.tiles % IG_SLOTS;
+    if (rem == 0 || rem * 2 > IG_SLOTS) return;       // the last round is at least half full
+    int s = IG_SLOTS / rem;                            // slices per tail tile: rem * s <= IG_SLOTS
+    if (s > 16) s = 16;
+    while (s > 1 && ksteps / s < 8) s--;               // a slice is at least 8 k-steps
+    if (s < 2) return;
+    g.tklen = (ksteps + s - 1) / s;
+    g.tsplit = (ksteps + g.tklen - 1) / g.tklen;       // no empty slices
+    g.full = g.tiles - rem;
+    g.fdTs = make_fastdiv(g.tsplit);
+}
+
 static void igemm_geometry(IgArgs &g, int N, int C, int H, int K, int stride) {
     g.N = N; g.C = C; g.K = K; g.H = H; g.W = H; g.Ho = H / stride; g.Wo = H / stride;
     g.HW = H * H; g.P = g.Ho * g.Wo;
@@ -486,9 +569,15 @@ int mi_igemm_fwd(hipStream_t st, mid_workspace *ws, const float *x, const float 
     g.mtiles = K / bm;
     g.tiles = g.mtiles * mi_cdiv(g.ncols, 128);
     g.fdM = make_fastdiv(g.mtiles);
+    g.cpt = C / IG_BK; g.fdCpt = make_fastdiv(g.cpt);
+    igemm_tail_plan(g, T * g.cpt, ws->wt_floats >= (size_t)T * C * K + IG_TAIL_FLOATS ? ws->wt + (size_t)T * C * K : nullptr);
     mi_prof_begin(st, igemm_fam(k), 2.0 * T * (double)g.ncols * C * K,
                   4.0 * ((double)N * C * g.HW + (double)T * C * K + (double)g.ncols * K));
-    const int rc = igemm_launch<IG_FWD>(st, dim3(g.tiles), ws->wt, x, y, nullptr, g, k, stride, bm);
+    int rc = igemm_launch<IG_FWD>(st, dim3(g.full + (g.tiles - g.full) * g.tsplit), ws->wt, x, y, nullptr, g, k, stride, bm);
+    if (!rc && g.tsplit > 1) {
+        if (bm == 128) hipLaunchKernelGGL((igemm_tail_reduce_kernel<IG_FWD, 128>), dim3(g.tiles - g.full), dim3(256), 0, st, y, nullptr, g);
+        else hipLaunchKernelGGL((igemm_tail_reduce_kernel<IG_FWD, 64>), dim3(g.tiles - g.full), dim3(256), 0, st, y, nullptr, g);
+    }
     mi_prof_end(st);
     if (rc) return rc;
     MI_LAUNCH_CHECK("igemm_kernel<fwd>");
@@ -511,9 +600,16 @@ int mi_igemm_dgrad(hipStream_t st, mid_workspace *ws, const float *w, const floa
     g.mtiles = C / bm;
     g.tiles = g.mtiles * mi_cdiv(g.ncols, 128);
     g.fdM = make_fastdiv(g.mtiles);
+    g.cpt = K / IG_BK; g.fdCpt = make_fastdiv(g.cpt);
+    // (stride 2: the four parity classes of unequal length already fill the rounds; no slicing)
+    igemm_tail_plan(g, T * g.cpt, stride == 1 && k == 3 && ws && ws->wt_floats >= (size_t)T * C * K + IG_TAIL_FLOATS ? ws->wt + (size_t)T * C * K : nullptr);
     mi_prof_begin(st, igemm_fam(k), 2.0 * T * (double)g.ncols * C * K,
                   4.0 * ((double)g.ncols * K + (double)T * C * K + (double)N * C * g.HW * (addend ? 2 : 1)));
-    const int rc = igemm_launch<IG_DGRAD>(st, dim3(g.tiles, stride == 2 ? 4 : 1), A, dy, dx, addend, g, k, stride, bm);
+    int rc = igemm_launch<IG_DGRAD>(st, dim3(g.full + (g.tiles - g.full) * g.tsplit, stride == 2 ? 4 : 1), A, dy, dx, addend, g, k, stride, bm);
+    if (!rc && g.tsplit > 1) {
+        if (bm == 128) hipLaunchKernelGGL((igemm_tail_reduce_kernel<IG_DGRAD, 128>), dim3(g.tiles - g.full), dim3(256), 0, st, dx, addend, g);
+        else hipLaunchKernelGGL((igemm_tail_reduce_kernel<IG_DGRAD, 64>), dim3(g.tiles - g.full), dim3(256), 0, st, dx, addend, g);
+    }
     mi_prof_end(st);
     if (rc) return rc;
     MI_LAUNCH_CHECK("igemm_kernel<dgrad>");
@@ -533,6 +629,7 @@ int mi_igemm_wgrad(hipStream_t st, mid_workspace *ws, const float *x, const floa
     g.tiles = g.mtiles * T * g.ctiles;
     g.fdM = make_fastdiv(g.mtiles);
     const int kd = N * g.P;
+    g.full = g.tiles; g.tsplit = 1; g.fdTs = make_fastdiv(1); g.cpt = 1; g.fdCpt = make_fastdiv(1);
     g.klen = mi_cdiv(mi_cdiv(kd, splits), IG_BK) * IG_BK;
     const int used = mi_cdiv(kd, g.klen);
     mi_prof_begin(st, igemm_fam(k), 2.0 * T * (double)kd * C * K,
