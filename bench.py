@@ -176,12 +176,12 @@ def main():
             # HBM traffic of that family from the committed rocprofv3 PMC passes (bench.py cannot run the profiler itself)
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-                key = {0: "dconv", 1: "wgradC", 2: "gemm", 3: "bn", 5: "pconv"}[dom]
+                key = {0: "dconv", 1: "wgradC", 2: "gemm", 3: "bn", 5: "igemm3x3"}[dom]
                 # the PMC passes count kernel launches, this run counts logical launches (the four concurrent stride-2 dgrad
                 # class kernels are one): convert through bytes per step
                 roof["traffic"] = round(pmc["families"][key]["hbm_GB_per_step_raw"] * 1e9 / (n / args.steps))
                 roof["traffic_note"] = ("HBM bytes per launch (FETCH_SIZE+WRITE_SIZE, separate --pmc passes, profiles/r1_pmc_traffic.json; "
-                                        "4-B/lane loads: gfx950 FETCH halving uncalibrated, raw value); algorithmic bytes per launch: %d" % round(by / max(n, 1)))
+                                        "4-B/lane gathers: gfx950 FETCH halving uncalibrated, raw value; Infinity-Cache hits are counted); algorithmic bytes per launch: %d" % round(by / max(n, 1)))
             except Exception:
                 pass
             roof["kernel"] = FAMILIES[dom]
