@@ -186,13 +186,21 @@ gemm_mfma_kernel(const float *__restrict__ A, const float *__restrict__ B, float
         else coff = (long)col * g.c_sn;
 #pragma unroll
         for (int i = 0; i < TM; i++) {
+            float ad[16];
+            if (addend) { // all 16 reads first: one memory latency per tile row block, not sixteen
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    ad[r] = row < g.M ? addend[coff + (long)row * g.c_sm] : 0.f;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row < g.M) {
                     const long o = coff + (long)row * g.c_sm;
                     float v = acc[i][j][r];
-                    if (addend) v += addend[o];
+                    if (addend) v += ad[r];
                     Cz[o] = v;
                 }
             }

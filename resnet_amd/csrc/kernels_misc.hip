@@ -13,16 +13,19 @@ static int ew_blocks(size_t n, int per = 256) {
 }
 
 // ---- max pool: window centred at stride*o, OOB skipped, strict '>' (first max wins), init -1024 ----
-__global__ void maxpool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int *__restrict__ idx, int NC,
-                                   int H, int Ho, int k, int stride) {
-    const size_t total = (size_t)NC * Ho * Ho;
+// (element counts < 2^32: 32-bit indices and precomputed fast division; the 64-bit % and / of a size_t index cost more
+// than the memory traffic of these kernels)
+__global__ void __launch_bounds__(256)
+maxpool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int *__restrict__ idx, uint32_t total, int H, int Ho,
+                   int k, int stride, FastDiv fdHo) {
     const int half = k / 2;
-    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
-        const int ow = (int)(o % Ho);
-        const size_t t = o / Ho;
-        const int oh = (int)(t % Ho);
-        const size_t nc = t / Ho;
-        const float *xp = x + nc * H * H;
+    for (uint32_t o = blockIdx.x * 256u + threadIdx.x; o < total; o += gridDim.x * 256u) {
+        const uint32_t t = fd_div(o, fdHo);
+        const int ow = (int)(o - t * Ho);
+        const uint32_t nc = fd_div(t, fdHo);
+        const int oh = (int)(t - nc * Ho);
+        const uint32_t pbase = nc * (uint32_t)(H * H);
+        const float *xp = x + pbase;
         float mv = -1024.f;
         int mi = -1024;
         for (int r = -half; r <= half; r++) {
@@ -32,7 +35,7 @@ __global__ void maxpool_fwd_kernel(const float *__restrict__ x, float *__restric
                 const int iw = stride * ow + c;
                 if (iw < 0 || iw >= H) continue;
                 const float v = xp[ih * H + iw];
-                if (v > mv) { mv = v; mi = (int)(nc * H * H) + ih * H + iw; }
+                if (v > mv) { mv = v; mi = (int)pbase + ih * H + iw; }
             }
         }
         y[o] = mv;
@@ -42,15 +45,15 @@ __global__ void maxpool_fwd_kernel(const float *__restrict__ x, float *__restric
 // Backward in gather form: each input element looks at the windows that contain it, in the reference's
 // (oh, ow) scan order, and keeps the LAST one whose arg-max it is -- the deterministic execution of the
 // reference's racy plain-store scatter (resnet.cu:493; memset 0 at :2186).
-__global__ void maxpool_bwd_kernel(const int *__restrict__ idx, const float *__restrict__ dy, float *__restrict__ dx,
-                                   int NC, int H, int Ho, int k, int stride) {
-    const size_t total = (size_t)NC * H * H;
+__global__ void __launch_bounds__(256)
+maxpool_bwd_kernel(const int *__restrict__ idx, const float *__restrict__ dy, float *__restrict__ dx, uint32_t total, int H,
+                   int Ho, int k, int stride, FastDiv fdH) {
     const int half = k / 2;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const int iw = (int)(e % H);
-        const size_t t = e / H;
-        const int ih = (int)(t % H);
-        const size_t nc = t / H;
+    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
+        const uint32_t t = fd_div(e, fdH);
+        const int iw = (int)(e - t * H);
+        const uint32_t nc = fd_div(t, fdH);
+        const int ih = (int)(t - nc * H);
         // outputs whose window covers (ih, iw): stride*oh - half <= ih <= stride*oh + half
         int oh_lo = (ih - half + stride - 1) / stride; if (ih - half < 0) oh_lo = 0;
         int oh_hi = (ih + half) / stride; if (oh_hi > Ho - 1) oh_hi = Ho - 1;
@@ -59,7 +62,7 @@ __global__ void maxpool_bwd_kernel(const int *__restrict__ idx, const float *__r
         float v = 0.f;
         for (int oh = oh_lo; oh <= oh_hi; oh++)
             for (int ow = ow_lo; ow <= ow_hi; ow++) {
-                const size_t o = (nc * Ho + oh) * Ho + ow;
+                const uint32_t o = (nc * Ho + oh) * Ho + ow;
                 if (idx[o] == (int)e) v = dy[o];
             }
         dx[e] = v;
@@ -202,14 +205,18 @@ int mid_lds_poison(mid_stream s) {
 int mid_maxpool_fwd(mid_stream s, const float *x, float *y, int *max_inds, int N, int C, int H, int k, int stride) {
     const int Ho = H / stride;
     const size_t total = (size_t)N * C * Ho * Ho;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)s, x, y, max_inds, N * C, H, Ho, k, stride);
+    if ((double)N * C * H * H >= 2147483648.0) { mi_record_error("mid_maxpool_fwd", "tensor too large for 32-bit indices"); return -2; }
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)s, x, y, max_inds, (uint32_t)total, H, Ho, k,
+                       stride, make_fastdiv(Ho));
     MI_LAUNCH_CHECK("maxpool_fwd_kernel");
     return 0;
 }
 int mid_maxpool_bwd(mid_stream s, const int *max_inds, const float *dy, float *dx, int N, int C, int H, int k, int stride) {
     const int Ho = H / stride;
     const size_t total = (size_t)N * C * H * H;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)s, max_inds, dy, dx, N * C, H, Ho, k, stride);
+    if ((double)total >= 2147483648.0) { mi_record_error("mid_maxpool_bwd", "tensor too large for 32-bit indices"); return -2; }
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)s, max_inds, dy, dx, (uint32_t)total, H, Ho, k,
+                       stride, make_fastdiv(H));
     MI_LAUNCH_CHECK("maxpool_bwd_kernel");
     return 0;
 }
