@@ -64,7 +64,7 @@ struct IgArgs {
 #define IG_ABLATE 0 /* experiments only: 1 = no staging after the first tile, 4 = no global loads */
 #endif
 
-template <int MODE, int KS, int S, int WMW>
+template <int MODE, int KS, int S, int WMW, bool VBP = false>
 __global__ void __launch_bounds__(256)
 igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float *__restrict__ Out,
              const float *__restrict__ addend, const IgArgs g) {
@@ -76,6 +76,9 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
     constexpr int LDB = (MODE == IG_WGRAD) ? 129 : 132;
     constexpr int NA4 = BM / 32;                 // fwd/dgrad: float4 loads of A per thread and tile
     constexpr int NAS = BM / 8;                  // wgrad: scalar loads of A per thread and tile
+    // 1x1 forward / dgrad with Ho*Wo % 4 == 0: four consecutive columns are four consecutive pixels of one image, so the
+    // B operand is staged with 16-byte loads / ds_write_b128 (4 per thread and k-step instead of 16 scalars)
+    constexpr bool VB = VBP && KS == 1 && MODE != IG_WGRAD;
     extern __shared__ __attribute__((aligned(16))) float ig_smem[];
     float *As = ig_smem;                   // [2][32][LDA]
     float *Bs = ig_smem + 2 * IG_BK * LDA; // [2][32][LDB]
@@ -125,16 +128,16 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
         const int Mdim = MODE == IG_FWD ? g.K : g.C;
         const int a_i = (tid & (BM / 4 - 1)) * 4, a_k = tid / (BM / 4);
         a_lane = (uint32_t)(a_k * Mdim + a_i) * 4u;
-        const int j = n0 + (tid & 127);
-        const bool jin = j < g.ncols;
+        const int j = VB ? n0 + (tid & 31) * 4 : n0 + (tid & 127);
+        const bool jin = j < g.ncols; // VB: ncols % 4 == 0, the four columns are in or out together
         const uint32_t jc = jin ? (uint32_t)j : (uint32_t)g.ncols - 1;
         const uint32_t n = fd_div(jc, g.fdP);
         const uint32_t p = jc - n * g.P;
         const uint32_t ho = fd_div(p, g.fdWo), wo = p - ho * g.Wo;
-        const int b_k = tid >> 7;
+        const int b_k = VB ? (tid >> 5) : 16 * (tid >> 7); // first B row of this thread (VB: rows b_k + 8q)
         if (MODE == IG_FWD) {
             // centre tap (S*ho, S*wo) is always inside the image
-            b_lane = (uint32_t)(n * g.C * g.HW + (S * ho) * g.W + S * wo + 16 * b_k * g.HW) * 4u;
+            b_lane = (uint32_t)(n * g.C * g.HW + (S * ho) * g.W + S * wo + b_k * g.HW) * 4u;
 #pragma unroll
             for (int t = 0; t < T; t++) {
                 const int hi = S * (int)ho - PAD + t / KS, wi = S * (int)wo - PAD + t % KS;
@@ -144,7 +147,7 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
             ntiles = T * (g.C / IG_BK);
         } else if (S == 1) {
             // one class, all taps: source pixel (h + PAD - r, w + PAD - s); (h, w) itself is the centre tap
-            b_lane = (uint32_t)(n * g.K * g.P + p + 16 * b_k * g.P) * 4u;
+            b_lane = (uint32_t)(n * g.K * g.P + p + b_k * g.P) * 4u;
 #pragma unroll
             for (int t = 0; t < T; t++) {
                 const int hs = (int)ho + PAD - t / KS, ws = (int)wo + PAD - t % KS;
@@ -157,7 +160,7 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
             ph = cls >> 1; pw = cls & 1;
             const int ntw = pw ? 2 : 1;
             ntaps = (ph ? 2 : 1) * ntw;
-            b_lane = (uint32_t)(n * g.K * g.P + p + 16 * b_k * g.P) * 4u; // (a, b) itself is always a valid source pixel
+            b_lane = (uint32_t)(n * g.K * g.P + p + b_k * g.P) * 4u; // (a, b) itself is always a valid source pixel
             for (int tt = 0; tt < ntaps; tt++) {
                 const int th = tt / ntw, tw = tt - th * ntw;
                 const int dh = (ph && th == 0) ? 1 : 0, dw = (pw && tw == 0) ? 1 : 0;
@@ -176,6 +179,7 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
 
     pf4 ra4[NA4];
     float ra[NAS], rb[16];
+    pf4 rb4[4];
     int sel_a = 1, sel_b = 1;   // whether the values held in ra / rb are real (else they are stored to LDS as 0)
     int ld_t = 0, ld_c0 = 0;    // next tile to fetch: tap (class tap) and first reduction channel
     if (MODE != IG_WGRAD && tail_id >= 0) { // a reduction slice: k-steps [it0, it0 + nt_slice) of the tile
@@ -224,8 +228,11 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
             }
             const size_t bstride = (MODE == IG_FWD ? (size_t)g.HW : (size_t)g.P) * 4;
             const size_t astride = (MODE == IG_FWD ? (size_t)g.K : (size_t)g.C) * 4;
-            rb[2 * p] = ldg(fb + (size_t)(2 * p) * bstride, fb_lane);
-            rb[2 * p + 1] = ldg(fb + (size_t)(2 * p + 1) * bstride, fb_lane);
+            if (VB) { if ((p & 1) == 0) rb4[p >> 1] = ldg4(fb + (size_t)(4 * p) * bstride, fb_lane); }
+            else {
+                rb[2 * p] = ldg(fb + (size_t)(2 * p) * bstride, fb_lane);
+                rb[2 * p + 1] = ldg(fb + (size_t)(2 * p + 1) * bstride, fb_lane);
+            }
             // A rows a_k + (32 / NA4) * q: spread over the parts
             if (p % (8 / NA4) == 0) ra4[p / (8 / NA4)] = ldg4(fa + (size_t)(4 * p) * astride, a_lane);
         } else {
@@ -266,9 +273,16 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
             bs[kx * LDB + row + 16 * p] = sel_b ? rb[2 * p] : 0.f;
             bs[kx * LDB + row + 16 * p + 8] = sel_b ? rb[2 * p + 1] : 0.f;
         } else {
-            const int bj = tid & 127, b_k = tid >> 7;
-            bs[(16 * b_k + 2 * p) * LDB + bj] = sel_b ? rb[2 * p] : 0.f;
-            bs[(16 * b_k + 2 * p + 1) * LDB + bj] = sel_b ? rb[2 * p + 1] : 0.f;
+            if (VB) {
+                if ((p & 1) == 0) {
+                    const pf4 z = {0.f, 0.f, 0.f, 0.f};
+                    *(pf4 *)(bs + ((tid >> 5) + 4 * p) * LDB + (tid & 31) * 4) = sel_b ? rb4[p >> 1] : z;
+                }
+            } else {
+                const int bj = tid & 127, b_k = 16 * (tid >> 7);
+                bs[(b_k + 2 * p) * LDB + bj] = sel_b ? rb[2 * p] : 0.f;
+                bs[(b_k + 2 * p + 1) * LDB + bj] = sel_b ? rb[2 * p + 1] : 0.f;
+            }
             if (p % (8 / NA4) == 0) {
                 const int a_i = (tid & (BM / 4 - 1)) * 4, a_k = tid / (BM / 4);
                 *(pf4 *)(as + (a_k + 4 * p) * LDA + a_i) = ra4[p / (8 / NA4)];
@@ -293,7 +307,9 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
         for (int q = 0; q < NA4; q++) asm volatile("" : "+v"(ra4[q]));
     }
 #pragma unroll
-    for (int q = 0; q < 16; q++) asm volatile("" : "+v"(rb[q]));
+    for (int q = 0; q < 16; q++) { if (!VB) asm volatile("" : "+v"(rb[q])); }
+#pragma unroll
+    for (int q = 0; q < 4; q++) { if (VB) asm volatile("" : "+v"(rb4[q])); }
     __syncthreads();
     for (int it = 0; it < ntiles; it++) {
         const int buf = it & 1;
@@ -459,14 +475,16 @@ enum { IGOP_FWD = 0, IGOP_DGRAD = 1, IGOP_WGRAD = 2 };
 //   2  (default) also every other 3x3 whose channel counts tile: measured on MI355X they are compute-bound, not
 //      HBM-bound (fp32 3x3 at C >= 64: >= 288 flop per byte), and the matrix cores run them at 90-119 TFLOP/s against
 //      60-75 on the vector ALUs
-// 1x1 forward and dgrad stay on gemm_mfma_kernel: with both operands contiguous its float4 staging issues half as many
-// VMEM instructions and the short reductions (C/32 = 2..64 k-steps) leave this kernel's deeper pipeline no room to pay.
+//   3  (experiment) also 1x1 forward / dgrad, with 16-byte staging of both operands (template flag VBP)
+// 1x1 forward and dgrad stay on gemm_mfma_kernel by default: measured equal (9.1 vs 9.2 ms/step over the 16 layer shapes)
+// -- with reductions of only C/32 = 2..64 k-steps these launches are bound by their prologue/epilogue and by the 56x56
+// layers' HBM traffic, not by the staging pipeline this kernel improves.
 int mi_igemm_supported(int op, int N, int C, int H, int K, int k, int stride) {
     const int mode = igemm_mode();
     if (!mode) return 0;
     if (!((k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2)))) return 0;
     if (H % stride || H / stride < 2) return 0;
-    if (k == 1 && op != IGOP_WGRAD) return 0;
+    if (k == 1 && op != IGOP_WGRAD && !(mode == 3 && (H * H) % 4 == 0)) return 0; // mode 3 (experiment): 1x1 fwd/dgrad here too
     if (k == 3 && mode == 1 && !(stride == 2 && K >= 2 * C && C >= 256)) return 0; // projections only
     if ((double)N * C * H * H >= 1073741824.0 || (double)N * K * (H / stride) * (H / stride) >= 1073741824.0) return 0; /* 32-bit byte offsets */
     if (op == IGOP_FWD) return C % 32 == 0 && K % 64 == 0;
@@ -526,7 +544,7 @@ static void igemm_geometry(IgArgs &g, int N, int C, int H, int K, int stride) {
     g.ncols = N * g.P;
     g.fdP = make_fastdiv(g.P); g.fdWo = make_fastdiv(g.Wo);
 }
-template <int MODE, int KS, int S, int WMW>
+template <int MODE, int KS, int S, int WMW, bool VB = false>
 static int igemm_launch_t(hipStream_t st, dim3 grid, const float *A, const float *B, float *out, const float *addend, const IgArgs &g) {
     constexpr int BM = 64 * WMW;
     constexpr int LDA = (MODE == IG_WGRAD) ? BM + 1 : BM + 4, LDB = (MODE == IG_WGRAD) ? 129 : 132;
@@ -534,13 +552,13 @@ static int igemm_launch_t(hipStream_t st, dim3 grid, const float *A, const float
     static int attr_set = 0;
     if (!attr_set) {
         if (lds > 64 * 1024 &&
-            hipFuncSetAttribute((const void *)igemm_kernel<MODE, KS, S, WMW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            hipFuncSetAttribute((const void *)igemm_kernel<MODE, KS, S, WMW, VB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             mi_record_error("igemm_kernel", "cannot raise the dynamic LDS limit");
             return -1;
         }
         attr_set = 1;
     }
-    hipLaunchKernelGGL((igemm_kernel<MODE, KS, S, WMW>), grid, dim3(256), lds, st, A, B, out, addend, g);
+    hipLaunchKernelGGL((igemm_kernel<MODE, KS, S, WMW, VB>), grid, dim3(256), lds, st, A, B, out, addend, g);
     return 0;
 }
 template <int MODE>
@@ -550,6 +568,9 @@ static int igemm_launch(hipStream_t st, dim3 grid, const float *A, const float *
     if (k == KS_ && stride == S_)                                                                         \
         return bm == 128 ? igemm_launch_t<MODE, KS_, S_, 2>(st, grid, A, B, out, addend, g)               \
                          : igemm_launch_t<MODE, KS_, S_, 1>(st, grid, A, B, out, addend, g);
+    if (MODE != IG_WGRAD && k == 1 && stride == 1 && g.P % 4 == 0)
+        return bm == 128 ? igemm_launch_t<MODE, 1, 1, 2, true>(st, grid, A, B, out, addend, g)
+                         : igemm_launch_t<MODE, 1, 1, 1, true>(st, grid, A, B, out, addend, g);
     IGL(1, 1) IGL(3, 1) IGL(3, 2)
 #undef IGL
     return -2;
