@@ -670,7 +670,7 @@ int mi_igemm_wgrad(hipStream_t st, mid_workspace *ws, const float *x, const floa
 extern "C" {
 
 /* re-laid weights, followed by the partial tiles of igemm's reduction-sliced tail workgroups (compute stream only) */
-size_t mid_conv_ws_wt_floats(int C, int K, int k) { return (size_t)k * k * C * K + (k == 3 ? mi_igemm_tail_floats() : 0); }
+size_t mid_conv_ws_wt_floats(int C, int K, int k) { return (size_t)k * k * C * K + (k <= 3 ? mi_igemm_tail_floats() : 0); }
 
 size_t mid_conv_ws_part_floats(int N, int C, int H, int K, int k, int stride) {
     if (mi_igemm_supported(IGOP_WGRAD, N, C, H, K, k, stride)) return mi_igemm_part_floats(N, C, H, K, k, stride);

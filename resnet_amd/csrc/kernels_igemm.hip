@@ -471,20 +471,18 @@ enum { IGOP_FWD = 0, IGOP_DGRAD = 1, IGOP_WGRAD = 2 };
 // Policy + shape gate.  RESNET_MI_IGEMM:
 //   0  off: every convolution on the older kernels (direct VALU 3x3/7x7, gemm_mfma_kernel 1x1)
 //   1  1x1 weight gradients and the 3x3/s2 projection shortcuts (K >= 2C) only: the bottleneck's own 3x3 convolutions
-//      stay on the direct VALU kernels
-//   2  (default) also every other 3x3 whose channel counts tile: measured on MI355X they are compute-bound, not
-//      HBM-bound (fp32 3x3 at C >= 64: >= 288 flop per byte), and the matrix cores run them at 90-119 TFLOP/s against
-//      60-75 on the vector ALUs
-//   3  (experiment) also 1x1 forward / dgrad, with 16-byte staging of both operands (template flag VBP)
-// 1x1 forward and dgrad stay on gemm_mfma_kernel by default: measured equal (9.1 vs 9.2 ms/step over the 16 layer shapes)
-// -- with reductions of only C/32 = 2..64 k-steps these launches are bound by their prologue/epilogue and by the 56x56
-// layers' HBM traffic, not by the staging pipeline this kernel improves.
+//      stay on the direct VALU kernels, 1x1 forward / dgrad on gemm_mfma_kernel
+//   2  (default) every 3x3 and 1x1 convolution whose channel counts tile.  Measured on MI355X the 3x3 layers are
+//      compute-bound, not HBM-bound (fp32 3x3 at C >= 64: >= 288 flop per byte), and the matrix cores run them at
+//      90-121 TFLOP/s against 60-75 on the vector ALUs.  1x1 forward / dgrad gain nothing from this kernel's staging
+//      pipeline (reductions of 2..64 k-steps: bound by prologue, epilogue and workgroup-count quantisation) but 8 %
+//      from its tile-height choice and sliced tail round (igemm_pick_bm, igemm_tail_plan): 19.0 -> 16.8 ms/step.
 int mi_igemm_supported(int op, int N, int C, int H, int K, int k, int stride) {
     const int mode = igemm_mode();
     if (!mode) return 0;
     if (!((k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2)))) return 0;
     if (H % stride || H / stride < 2) return 0;
-    if (k == 1 && op != IGOP_WGRAD && !(mode == 3 && (H * H) % 4 == 0)) return 0; // mode 3 (experiment): 1x1 fwd/dgrad here too
+    if (k == 1 && op != IGOP_WGRAD && mode < 2) return 0;
     if (k == 3 && mode == 1 && !(stride == 2 && K >= 2 * C && C >= 256)) return 0; // projections only
     if ((double)N * C * H * H >= 1073741824.0 || (double)N * K * (H / stride) * (H / stride) >= 1073741824.0) return 0; /* 32-bit byte offsets */
     if (op == IGOP_FWD) return C % 32 == 0 && K % 64 == 0;
@@ -538,6 +536,32 @@ static void igemm_tail_plan(IgArgs &g, int ksteps, float *tailbuf) {
     g.fdTs = make_fastdiv(g.tsplit);
 }
 
+// Rows per workgroup tile.  64-row tiles do ~10% less work per cycle than 128-row ones but halve the granularity: they win
+// where the 128-row grid ends in a mostly empty round that is too full to slice (e.g. 1024->256 @14: 784 tiles = 1.53
+// rounds -> two rounds; 1568 half tiles = 3.06 rounds with a sliced tail).
+static int igemm_pick_bm(int M, int coltiles, int ksteps) {
+    if (M % 128) return 64;
+    double best = 0;
+    int pick = 128;
+    for (int bm = 128; bm >= 64; bm -= 64) {
+        const long B = (long)(M / bm) * coltiles;
+        const long rem = B % IG_SLOTS;
+        double tail = 0;
+        if (rem) {
+            int s = (int)(IG_SLOTS / rem);
+            if (s > 16) s = 16;
+            while (s > 1 && ksteps / s < 8) s--;
+            tail = rem * 2 > IG_SLOTS || s < 2 ? 1.0 : 1.0 / s + 0.03;
+        }
+        const double t = ((double)(B / IG_SLOTS) + tail) * (bm == 128 ? 1.0 : 0.55);
+        if (bm == 128 || t < best * 0.97) { if (bm == 128 || t < best) { best = t; pick = bm; } }
+    }
+    static int force = -1;
+    if (force < 0) { const char *e = getenv("RESNET_MI_IGEMM_BM"); force = e ? atoi(e) : 0; }
+    if (force == 64 || (force == 128 && M % 128 == 0)) return force;
+    return pick;
+}
+
 static void igemm_geometry(IgArgs &g, int N, int C, int H, int K, int stride) {
     g.N = N; g.C = C; g.K = K; g.H = H; g.W = H; g.Ho = H / stride; g.Wo = H / stride;
     g.HW = H * H; g.P = g.Ho * g.Wo;
@@ -586,7 +610,7 @@ int mi_igemm_fwd(hipStream_t st, mid_workspace *ws, const float *x, const float 
     MI_LAUNCH_CHECK("igemm_wt_kernel");
     IgArgs g = {};
     igemm_geometry(g, N, C, H, K, stride);
-    const int bm = K % 128 == 0 ? 128 : 64;
+    const int bm = igemm_pick_bm(K, mi_cdiv(g.ncols, 128), T * (C / IG_BK));
     g.mtiles = K / bm;
     g.tiles = g.mtiles * mi_cdiv(g.ncols, 128);
     g.fdM = make_fastdiv(g.mtiles);
@@ -617,13 +641,13 @@ int mi_igemm_dgrad(hipStream_t st, mid_workspace *ws, const float *w, const floa
     }
     IgArgs g = {};
     igemm_geometry(g, N, C, H, K, stride);
-    const int bm = C % 128 == 0 ? 128 : 64;
+    const int bm = stride == 1 ? igemm_pick_bm(C, mi_cdiv(g.ncols, 128), T * (K / IG_BK)) : (C % 128 == 0 ? 128 : 64);
     g.mtiles = C / bm;
     g.tiles = g.mtiles * mi_cdiv(g.ncols, 128);
     g.fdM = make_fastdiv(g.mtiles);
     g.cpt = K / IG_BK; g.fdCpt = make_fastdiv(g.cpt);
     // (stride 2: the four parity classes of unequal length already fill the rounds; no slicing)
-    igemm_tail_plan(g, T * g.cpt, stride == 1 && k == 3 && ws && ws->wt_floats >= (size_t)T * C * K + IG_TAIL_FLOATS ? ws->wt + (size_t)T * C * K : nullptr);
+    igemm_tail_plan(g, T * g.cpt, stride == 1 && ws && ws->wt_floats >= (size_t)T * C * K + IG_TAIL_FLOATS ? ws->wt + (size_t)T * C * K : nullptr);
     mi_prof_begin(st, igemm_fam(k), 2.0 * T * (double)g.ncols * C * K,
                   4.0 * ((double)g.ncols * K + (double)T * C * K + (double)N * C * g.HW * (addend ? 2 : 1)));
     int rc = igemm_launch<IG_DGRAD>(st, dim3(g.full + (g.tiles - g.full) * g.tsplit, stride == 2 ? 4 : 1), A, dy, dx, addend, g, k, stride, bm);

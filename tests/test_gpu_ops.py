@@ -216,13 +216,13 @@ def test_layout(ops):
     assert np.array_equal(ops.nhwc_to_nchw(x), nchw(x))
 
 
-@pytest.mark.parametrize("mode", ["0", "1", "3"])
+@pytest.mark.parametrize("mode", ["0", "1"])
 def test_conv_parity_on_the_other_kernel_routes(mode):
     """RESNET_MI_IGEMM selects which kernels a convolution runs on (kernels_igemm.hip: mi_igemm_supported).  The default
-    (2) sends every tiling 3x3 and the 1x1 weight gradients to the MFMA implicit GEMM; 1 keeps the bottleneck's own 3x3
-    convolutions on the direct VALU kernels (only the projection shortcuts and 1x1 wgrad on MFMA); 0 uses the direct
-    kernels and gemm_mfma_kernel for everything; 3 (experiment, no faster) also sends 1x1 forward/dgrad to the implicit
-    GEMM with 16-byte staging of both operands.  The routes are read once per process, so the conv parity tests of
+    (2) sends every tiling 3x3 and 1x1 convolution to the MFMA implicit GEMM; 1 keeps the bottleneck's own 3x3
+    convolutions on the direct VALU kernels and 1x1 forward/dgrad on gemm_mfma_kernel (only the projection shortcuts and
+    1x1 wgrad on the implicit GEMM); 0 uses the direct kernels and gemm_mfma_kernel for everything.  The routes are read
+    once per process, so the conv parity tests of
     this file are re-run in a child process per route: every kernel family stays pinned to the oracle at the
     ResNet-50 layer shapes whichever route is the default."""
     import os
