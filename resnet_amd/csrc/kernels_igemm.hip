@@ -402,7 +402,9 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
 }
 
 // Sum of the reduction slices of the tail tiles, in slice order (deterministic), written where the tile's own epilogue
-// would have put it.  grid = number of tail tiles; thread = one column, BM/2 rows.
+// would have put it.  grid = (tail tiles, BM / 16): a workgroup owns a 16-row slab of one tile, a thread one column and
+// 8 rows of it -- the 8 x tsplit loads of a thread are independent (the first form, one thread per column looping over
+// all rows, was latency-bound: 76 us per launch).
 template <int MODE, int BM>
 __global__ void __launch_bounds__(256)
 igemm_tail_reduce_kernel(float *__restrict__ Out, const float *__restrict__ addend, const IgArgs g) {
@@ -416,13 +418,21 @@ igemm_tail_reduce_kernel(float *__restrict__ Out, const float *__restrict__ adde
     size_t coff, rstride;
     if (MODE == IG_FWD) { coff = (size_t)n * g.K * g.P + p; rstride = (size_t)g.P; }
     else { coff = (size_t)n * g.C * g.HW + p; rstride = (size_t)g.HW; }
-    const float *tb = g.tailbuf + (size_t)blockIdx.x * g.tsplit * (BM * 128) + (threadIdx.x & 127);
-    for (int row = threadIdx.x >> 7; row < BM; row += 2) {
-        float v = 0.f;
-        for (int z = 0; z < g.tsplit; z++) v += tb[(size_t)z * (BM * 128) + row * 128];
-        const size_t o = coff + (size_t)(m0 + row) * rstride;
-        if (MODE == IG_DGRAD && addend) v += addend[o];
-        Out[o] = v;
+    const int row0 = (int)blockIdx.y * 16 + (int)(threadIdx.x >> 7) * 8;
+    const float *tb = g.tailbuf + (size_t)blockIdx.x * g.tsplit * (BM * 128) + (size_t)row0 * 128 + (threadIdx.x & 127);
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = 0.f;
+    for (int z = 0; z < g.tsplit; z++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] += tb[(size_t)z * (BM * 128) + i * 128];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const size_t o = coff + (size_t)(m0 + row0 + i) * rstride;
+        float r = v[i];
+        if (MODE == IG_DGRAD && addend) r += addend[o];
+        Out[o] = r;
     }
 }
 
@@ -516,8 +526,8 @@ size_t mi_igemm_tail_floats(void) { return igemm_mode() ? IG_TAIL_FLOATS : 0; }
 // projection has 1568 tiles = 3.06 rounds).  The `rem` tiles of that last round are cut into s = IG_SLOTS / rem slices along
 // the reduction, each slice a workgroup of its own: the round shrinks to 1/s of its length (b13 projection forward
 // 104.9 -> 111.3 TFLOP/s).  Measured and rejected: slicing a last round that is more than half full into more than
-// IG_SLOTS slices (several short rounds) -- the partial-tile traffic and the second-stage launch cost more than the
-// idle slots did (256@14 forward 0.63 -> 0.71 ms).
+// IG_SLOTS slices (several short rounds) -- no gain over leaving it whole (3x3 forward 8.8 vs 8.8 ms/step, projections
+// 12.3 vs 12.1).
 static void igemm_tail_plan(IgArgs &g, int ksteps, float *tailbuf) {
     g.full = g.tiles; g.tsplit = 1; g.tklen = ksteps; g.tailbuf = tailbuf;
     g.fdTs = make_fastdiv(1);
@@ -525,7 +535,8 @@ static void igemm_tail_plan(IgArgs &g, int ksteps, float *tailbuf) {
     if (on < 0) { const char *e = getenv("RESNET_MI_IGEMM_TAIL"); on = e ? atoi(e) : 1; }
     if (!on || !tailbuf) return;
     const int rem = g.tiles % IG_SLOTS;
-    if (rem == 0 || rem * 2 > IG_SLOTS) return;       // the last round is at least half full
+    if (rem == 0) return;
+    if (rem * 2 > IG_SLOTS) return;                    // the last round is at least half full
     int s = IG_SLOTS / rem;                            // slices per tail tile: rem * s <= IG_SLOTS
     if (s > 16) s = 16;
     while (s > 1 && ksteps / s < 8) s--;               // a slice is at least 8 k-steps
@@ -620,8 +631,8 @@ int mi_igemm_fwd(hipStream_t st, mid_workspace *ws, const float *x, const float 
                   4.0 * ((double)N * C * g.HW + (double)T * C * K + (double)g.ncols * K));
     int rc = igemm_launch<IG_FWD>(st, dim3(g.full + (g.tiles - g.full) * g.tsplit), ws->wt, x, y, nullptr, g, k, stride, bm);
     if (!rc && g.tsplit > 1) {
-        if (bm == 128) hipLaunchKernelGGL((igemm_tail_reduce_kernel<IG_FWD, 128>), dim3(g.tiles - g.full), dim3(256), 0, st, y, nullptr, g);
-        else hipLaunchKernelGGL((igemm_tail_reduce_kernel<IG_FWD, 64>), dim3(g.tiles - g.full), dim3(256), 0, st, y, nullptr, g);
+        if (bm == 128) hipLaunchKernelGGL((igemm_tail_reduce_kernel<IG_FWD, 128>), dim3(g.tiles - g.full, 8), dim3(256), 0, st, y, nullptr, g);
+        else hipLaunchKernelGGL((igemm_tail_reduce_kernel<IG_FWD, 64>), dim3(g.tiles - g.full, 4), dim3(256), 0, st, y, nullptr, g);
     }
     mi_prof_end(st);
     if (rc) return rc;
@@ -652,8 +663,8 @@ int mi_igemm_dgrad(hipStream_t st, mid_workspace *ws, const float *w, const floa
                   4.0 * ((double)g.ncols * K + (double)T * C * K + (double)N * C * g.HW * (addend ? 2 : 1)));
     int rc = igemm_launch<IG_DGRAD>(st, dim3(g.full + (g.tiles - g.full) * g.tsplit, stride == 2 ? 4 : 1), A, dy, dx, addend, g, k, stride, bm);
     if (!rc && g.tsplit > 1) {
-        if (bm == 128) hipLaunchKernelGGL((igemm_tail_reduce_kernel<IG_DGRAD, 128>), dim3(g.tiles - g.full), dim3(256), 0, st, dx, addend, g);
-        else hipLaunchKernelGGL((igemm_tail_reduce_kernel<IG_DGRAD, 64>), dim3(g.tiles - g.full), dim3(256), 0, st, dx, addend, g);
+        if (bm == 128) hipLaunchKernelGGL((igemm_tail_reduce_kernel<IG_DGRAD, 128>), dim3(g.tiles - g.full, 8), dim3(256), 0, st, dx, addend, g);
+        else hipLaunchKernelGGL((igemm_tail_reduce_kernel<IG_DGRAD, 64>), dim3(g.tiles - g.full, 4), dim3(256), 0, st, dx, addend, g);
     }
     mi_prof_end(st);
     if (rc) return rc;
