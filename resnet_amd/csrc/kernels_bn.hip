@@ -115,6 +115,46 @@ bn_stats_kernel(const float *__restrict__ x, float *__restrict__ partial, int N,
     }
 }
 
+// Statistics partials left by a convolution (kernels_igemm.hip: three planes [np][C] of count, mean, M2; channel
+// contiguous) -> the (channel, split) partial table bn_finalize_kernel reads.  grid (ceil(C / 64), G): a workgroup
+// merges one chunk of the np partials for 64 channels, four partials in flight per channel, in a fixed order.
+__global__ void __launch_bounds__(256)
+bn_parts_merge_kernel(const float *__restrict__ parts, int np, int C, float *__restrict__ partial) {
+    const int cx = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const int chunk = (np + gridDim.y - 1) / gridDim.y;
+    const int p0 = blockIdx.y * chunk, p1 = min(np, p0 + chunk);
+    const size_t plane = (size_t)np * C;
+    Wel w = {0.f, 0.f, 0.f};
+    if (c < C) {
+        int p = p0 + sg;
+        for (; p + 7 * 4 < p1; p += 8 * 4) { // eight partials in flight per thread (a load per merge was latency-bound)
+            Wel b[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const size_t o = (size_t)(p + 4 * u) * C + c;
+                b[u].n = parts[o]; b[u].mean = parts[plane + o]; b[u].m2 = parts[2 * plane + o];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) w = wel_merge(w, b[u]);
+        }
+        for (; p < p1; p += 4) {
+            const size_t o = (size_t)p * C + c;
+            Wel b = {parts[o], parts[plane + o], parts[2 * plane + o]};
+            w = wel_merge(w, b);
+        }
+    }
+    __shared__ Wel sh[4][64];
+    sh[sg][cx] = w;
+    __syncthreads();
+    if (sg == 0 && c < C) {
+        Wel r = sh[0][cx];
+        for (int i = 1; i < 4; i++) r = wel_merge(r, sh[i][cx]);
+        float *o = partial + ((size_t)c * BN_SPLIT_MAX + blockIdx.y) * 3;
+        o[0] = r.n; o[1] = r.mean; o[2] = r.m2;
+    }
+}
+
 // per-channel finalize: merges the split partials in fixed order; writes mean / biased var
 __global__ void bn_finalize_kernel(const float *__restrict__ partial, int nsplit, int C, float *__restrict__ means,
                                    float *__restrict__ vars) {
@@ -313,6 +353,23 @@ static int ew_blocks(size_t nvec) {
 extern "C" {
 size_t mid_bn_ws_floats(int C) { return (size_t)C * BN_SPLIT_MAX * 3; }
 
+size_t mid_bn_parts_floats(int N, int K, int Ho) { return (size_t)3 * (size_t)mi_cdiv((long)N * Ho * Ho, 128) * 4 * K; }
+
+static int bn_fwd_apply(hipStream_t st, const float *x, const float *gamma, const float *beta, const float *residual,
+                        const float *means, const float *vars, float *y, float *xhat_out, float *norm_out, int N, int C, int P,
+                        float eps, int relu) {
+    const size_t total = (size_t)N * C * P;
+    const FastDiv fdP = make_fastdiv(P), fdC = make_fastdiv(C);
+    if ((P & 3) == 0)
+        hipLaunchKernelGGL((bn_apply_kernel<true>), dim3(ew_blocks(total / 4)), dim3(256), 0, st, x, gamma, beta, means,
+                           vars, residual, y, xhat_out, norm_out, C, P, fdP, fdC, total, eps, relu);
+    else
+        hipLaunchKernelGGL((bn_apply_kernel<false>), dim3(ew_blocks(total)), dim3(256), 0, st, x, gamma, beta, means,
+                           vars, residual, y, xhat_out, norm_out, C, P, fdP, fdC, total, eps, relu);
+    MI_LAUNCH_CHECK("bn_apply_kernel");
+    return 0;
+}
+
 int mid_bn_fwd(mid_stream s, float *ws, const float *x, const float *gamma, const float *beta, const float *residual,
                float *means, float *vars, float *y, float *xhat_out, float *norm_out, int N, int C, int P, float eps,
                int relu) {
@@ -324,17 +381,29 @@ int mid_bn_fwd(mid_stream s, float *ws, const float *x, const float *gamma, cons
     MI_LAUNCH_CHECK("bn_stats_kernel");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(mi_cdiv(C, 64)), dim3(64), 0, st, ws, ns, C, means, vars);
     MI_LAUNCH_CHECK("bn_finalize_kernel");
-    const size_t total = (size_t)N * C * P;
-    const FastDiv fdP = make_fastdiv(P), fdC = make_fastdiv(C);
-    if ((P & 3) == 0)
-        hipLaunchKernelGGL((bn_apply_kernel<true>), dim3(ew_blocks(total / 4)), dim3(256), 0, st, x, gamma, beta, means,
-                           vars, residual, y, xhat_out, norm_out, C, P, fdP, fdC, total, eps, relu);
-    else
-        hipLaunchKernelGGL((bn_apply_kernel<false>), dim3(ew_blocks(total)), dim3(256), 0, st, x, gamma, beta, means,
-                           vars, residual, y, xhat_out, norm_out, C, P, fdP, fdC, total, eps, relu);
+    const int rc = bn_fwd_apply(st, x, gamma, beta, residual, means, vars, y, xhat_out, norm_out, N, C, P, eps, relu);
     mi_prof_end(st);
-    MI_LAUNCH_CHECK("bn_apply_kernel");
-    return 0;
+    return rc;
+}
+
+int mid_bn_fwd_parts(mid_stream s, float *ws, const mid_bn_parts *parts, const float *x, const float *gamma, const float *beta,
+                     const float *residual, float *means, float *vars, float *y, float *xhat_out, float *norm_out, int N,
+                     int C, int P, float eps, int relu) {
+    if (!parts || parts->nparts <= 0)
+        return mid_bn_fwd(s, ws, x, gamma, beta, residual, means, vars, y, xhat_out, norm_out, N, C, P, eps, relu);
+    hipStream_t st = (hipStream_t)s;
+    int G = parts->nparts / 64;
+    if (G < 1) G = 1;
+    if (G > BN_SPLIT_MAX) G = BN_SPLIT_MAX;
+    // the statistics pass over x is gone: 2 passes (+1 fused add) instead of 3
+    mi_prof_begin(st, MI_FAM_BN, 0.0, 4.0 * (double)N * C * P * (residual ? 3 : 2));
+    hipLaunchKernelGGL(bn_parts_merge_kernel, dim3(mi_cdiv(C, 64), G), dim3(256), 0, st, parts->buf, parts->nparts, C, ws);
+    MI_LAUNCH_CHECK("bn_parts_merge_kernel");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(mi_cdiv(C, 64)), dim3(64), 0, st, ws, G, C, means, vars);
+    MI_LAUNCH_CHECK("bn_finalize_kernel");
+    const int rc = bn_fwd_apply(st, x, gamma, beta, residual, means, vars, y, xhat_out, norm_out, N, C, P, eps, relu);
+    mi_prof_end(st);
+    return rc;
 }
 
 int mid_bn_bwd(mid_stream s, float *ws, const float *x, const float *gamma, const float *beta, const float *means,

@@ -661,7 +661,7 @@ int mi_igemm_supported(int op, int N, int C, int H, int K, int k, int stride);
 size_t mi_igemm_part_floats(int N, int C, int H, int K, int k, int stride);
 size_t mi_igemm_tail_floats(void);
 int mi_igemm_fwd(hipStream_t st, mid_workspace *ws, const float *x, const float *w, float *y, int N, int C, int H, int K, int k,
-                 int stride);
+                 int stride, mid_bn_parts *parts);
 int mi_igemm_dgrad(hipStream_t st, mid_workspace *ws, const float *w, const float *dy, float *dx, const float *addend, int N,
                    int C, int H, int K, int k, int stride);
 int mi_igemm_wgrad(hipStream_t st, mid_workspace *ws, const float *x, const float *dy, float *dw, int N, int C, int H, int K, int k,
@@ -684,8 +684,13 @@ size_t mid_conv_ws_part_floats(int N, int C, int H, int K, int k, int stride) {
 
 int mid_conv_fwd(mid_stream s, mid_workspace *ws, const float *x, const float *w, float *y, int N, int C, int H, int K,
                  int k, int stride) {
+    return mid_conv_fwd_stats(s, ws, x, w, y, N, C, H, K, k, stride, nullptr);
+}
+int mid_conv_fwd_stats(mid_stream s, mid_workspace *ws, const float *x, const float *w, float *y, int N, int C, int H, int K,
+                       int k, int stride, mid_bn_parts *parts) {
     hipStream_t st = (hipStream_t)s;
-    if (mi_igemm_supported(IGOP_FWD, N, C, H, K, k, stride)) return mi_igemm_fwd(st, ws, x, w, y, N, C, H, K, k, stride);
+    if (parts) parts->nparts = 0;
+    if (mi_igemm_supported(IGOP_FWD, N, C, H, K, k, stride)) return mi_igemm_fwd(st, ws, x, w, y, N, C, H, K, k, stride, parts);
     if (k == 1 && stride == 1) return mi_conv1x1_fwd(st, x, w, y, N, C, H * H, K);
     if (!((k == 3 && (stride == 1 || stride == 2)) || (k == 7 && stride == 2)) || H % stride) {
         mi_record_error("mid_conv_fwd", "unsupported kernel/stride");

@@ -57,7 +57,35 @@ struct IgArgs {
     int full, tsplit, tklen, cpt; // cpt: k-steps per tap
     FastDiv fdTs, fdCpt;
     float *tailbuf;
+    // forward: batch-norm statistics of the output fused into the epilogue (three planes [bn_np][K] of count, mean, M2 over
+    // the columns of a (tile, 128/PPT-column group); PPT = 2 for 128-row tiles, 4 for 64-row tiles); nullptr = off
+    float *bn_part;
+    int bn_np;
 };
+
+// (count, mean, M2) of one value per lane over the first nv lanes of each 32-lane half: shifted sums about the half's
+// first value (no cancellation), butterfly over the half.  Result valid in every lane of the half.
+__device__ __forceinline__ void ig_half_stats(float x, int nv, int l31, float &mean, float &m2) {
+    const float s = __shfl(x, (int)(threadIdx.x & 32), 64);
+    const float d = l31 < nv ? x - s : 0.f;
+    float sd = d, sq = d * d;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { sd += __shfl_xor(sd, o, 64); sq += __shfl_xor(sq, o, 64); }
+    const float inv = nv > 0 ? 1.0f / (float)nv : 0.f;
+    mean = s + sd * inv;
+    m2 = fmaxf(sq - sd * sd * inv, 0.f);
+    if (nv <= 0) { mean = 0.f; m2 = 0.f; }
+}
+// Chan merge of two groups (na, ma, qa) <- (nb, mb, qb)
+__device__ __forceinline__ void ig_merge(float &na, float &ma, float &qa, float nb, float mb, float qb) {
+    const float n = na + nb;
+    if (n > 0.f) {
+        const float dlt = mb - ma, f = nb / n;
+        ma = ma + dlt * f;
+        qa = qa + qb + dlt * dlt * na * f;
+    }
+    na = n;
+}
 
 #define IG_BK 32
 #ifndef IG_ABLATE
@@ -399,6 +427,46 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
             }
         }
     }
+
+    // ---- forward: batch-norm statistics of this tile (the separate read of the whole output is gone) ----
+    // Each wave transposes its 64 x WNC accumulator tile through LDS (16-byte stores, XOR-swizzled: conflict-free both ways)
+    // so that lane = row; the lane then walks its row's WNC values alone -- no cross-lane traffic (a butterfly per row cost
+    // 700 ds_bpermute per wave and made the step 5 % slower than the separate pass it replaced).
+    if (MODE == IG_FWD && g.bn_part) {
+        constexpr int PPT = 4 / WMW;               // column groups per tile: one per wave column (wn)
+        float *tw = ig_smem + wave * (WNC * 64);   // [WNC cols][64 rows]; the LDS tiles are dead after the loop's last barrier
+        const int l31 = lane & 31;
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int col = j * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) {
+                    const int row4 = i * 8 + rg * 2 + (lane >> 5); // rows 4*row4 .. 4*row4+3  (row = i*32 + 8*rg + 4*(lane>>5) + (r&3))
+                    pf4 q4 = {acc[i][j][rg * 4 + 0], acc[i][j][rg * 4 + 1], acc[i][j][rg * 4 + 2], acc[i][j][rg * 4 + 3]};
+                    *(pf4 *)(tw + col * 64 + ((row4 ^ (col & 15)) << 2)) = q4;
+                }
+        }
+        // (each wave reads only what it wrote: no workgroup barrier; the LDS ops of a wave complete in order)
+        const int nv = min(WNC, max(0, g.ncols - (n0 + wn * WNC))); // valid columns of this wave (a prefix)
+        const int row = lane;
+        const float s0 = tw[(((row >> 2) ^ 0) << 2) + (row & 3)];   // column 0: the shift
+        float sd = 0.f, sq = 0.f;
+#pragma unroll 8
+        for (int c = 0; c < WNC; c++) {
+            const float x = tw[c * 64 + ((((row >> 2) ^ (c & 15))) << 2) + (row & 3)];
+            const float d = c < nv ? x - s0 : 0.f;
+            sd += d;
+            sq = fmaf(d, d, sq);
+        }
+        const float inv = nv > 0 ? 1.0f / (float)nv : 0.f;
+        const size_t plane = (size_t)g.bn_np * g.K;
+        const size_t o = (size_t)(ct * PPT + wn) * g.K + m0 + wm * 64 + row;
+        g.bn_part[o] = (float)nv;
+        g.bn_part[plane + o] = nv > 0 ? s0 + sd * inv : 0.f;
+        g.bn_part[2 * plane + o] = fmaxf(sq - sd * sd * inv, 0.f);
+    }
 }
 
 // Sum of the reduction slices of the tail tiles, in slice order (deterministic), written where the tile's own epilogue
@@ -412,9 +480,10 @@ igemm_tail_reduce_kernel(float *__restrict__ Out, const float *__restrict__ adde
     const uint32_t ct = fd_div(L, g.fdM);
     const int m0 = (int)(L - ct * g.mtiles) * BM;
     const int col = (int)ct * 128 + (threadIdx.x & 127);
-    if (col >= g.ncols) return;
-    const uint32_t n = fd_div((uint32_t)col, g.fdP);
-    const uint32_t p = (uint32_t)col - n * g.P;
+    const bool cok = col < g.ncols;
+    const uint32_t jc = cok ? (uint32_t)col : 0u;
+    const uint32_t n = fd_div(jc, g.fdP);
+    const uint32_t p = jc - n * g.P;
     size_t coff, rstride;
     if (MODE == IG_FWD) { coff = (size_t)n * g.K * g.P + p; rstride = (size_t)g.P; }
     else { coff = (size_t)n * g.C * g.HW + p; rstride = (size_t)g.HW; }
@@ -427,12 +496,38 @@ igemm_tail_reduce_kernel(float *__restrict__ Out, const float *__restrict__ adde
 #pragma unroll
         for (int i = 0; i < 8; i++) v[i] += tb[(size_t)z * (BM * 128) + i * 128];
     }
+    if (cok) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const size_t o = coff + (size_t)(m0 + row0 + i) * rstride;
-        float r = v[i];
-        if (MODE == IG_DGRAD && addend) r += addend[o];
-        Out[o] = r;
+        for (int i = 0; i < 8; i++) {
+            const size_t o = coff + (size_t)(m0 + row0 + i) * rstride;
+            float r = v[i];
+            if (MODE == IG_DGRAD && addend) r += addend[o];
+            Out[o] = r;
+        }
+    }
+    if (MODE == IG_FWD && g.bn_part) { // same partials as the main kernel's epilogue writes for an unsliced tile
+        constexpr int PPT = BM == 128 ? 2 : 4;
+        const int lane = threadIdx.x & 63, l31 = lane & 31;
+        const int c32 = (int)ct * 128 + (int)(threadIdx.x & 127 & ~31); // first column of this lane's 32-column half
+        const int nv = min(32, max(0, g.ncols - c32));
+        const size_t plane = (size_t)g.bn_np * g.K;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            float mj, qj, nj = (float)nv;
+            ig_half_stats(v[i], nv, l31, mj, qj);
+            int pp = (int)(threadIdx.x & 127) >> 5; // 32-column group of the tile
+            if (PPT == 2) { // merge the two halves of the wave: 64-column groups
+                const float n2 = __shfl_xor(nj, 32, 64), m2o = __shfl_xor(mj, 32, 64), q2 = __shfl_xor(qj, 32, 64);
+                if (lane == 0) ig_merge(nj, mj, qj, n2, m2o, q2);
+                pp >>= 1;
+            }
+            if (PPT == 2 ? lane == 0 : l31 == 0) {
+                const size_t o = (size_t)(ct * PPT + pp) * g.K + m0 + row0 + i;
+                g.bn_part[o] = nj;
+                g.bn_part[plane + o] = mj;
+                g.bn_part[2 * plane + o] = qj;
+            }
+        }
     }
 }
 
@@ -613,7 +708,7 @@ static int igemm_launch(hipStream_t st, dim3 grid, const float *A, const float *
 static int igemm_fam(int k) { return k == 1 ? MI_FAM_GEMM : MI_FAM_PCONV; }
 
 int mi_igemm_fwd(hipStream_t st, mid_workspace *ws, const float *x, const float *w, float *y, int N, int C, int H, int K, int k,
-                 int stride) {
+                 int stride, mid_bn_parts *parts) {
     const int T = k * k;
     if (!ws || ws->wt_floats < (size_t)T * C * K) { mi_record_error("mi_igemm_fwd", "workspace too small"); return -3; }
     if (k == 1) hipLaunchKernelGGL(igemm_wt_kernel<1>, dim3(C / 32, K / 32), dim3(256), 0, st, w, ws->wt, K, C, 1);
@@ -627,6 +722,11 @@ int mi_igemm_fwd(hipStream_t st, mid_workspace *ws, const float *x, const float 
     g.fdM = make_fastdiv(g.mtiles);
     g.cpt = C / IG_BK; g.fdCpt = make_fastdiv(g.cpt);
     igemm_tail_plan(g, T * g.cpt, ws->wt_floats >= (size_t)T * C * K + IG_TAIL_FLOATS ? ws->wt + (size_t)T * C * K : nullptr);
+    if (parts) {
+        parts->nparts = 0;
+        const int np = mi_cdiv(g.ncols, 128) * (bm == 128 ? 2 : 4);
+        if (parts->buf && parts->floats >= (size_t)3 * np * K) { g.bn_part = parts->buf; g.bn_np = np; parts->nparts = np; }
+    }
     mi_prof_begin(st, igemm_fam(k), 2.0 * T * (double)g.ncols * C * K,
                   4.0 * ((double)N * C * g.HW + (double)T * C * K + (double)g.ncols * K));
     int rc = igemm_launch<IG_FWD>(st, dim3(g.full + (g.tiles - g.full) * g.tsplit), ws->wt, x, y, nullptr, g, k, stride, bm);

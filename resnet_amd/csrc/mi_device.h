@@ -60,6 +60,17 @@ typedef struct {
 /* 3x3 / 7x7 direct (LDS-tiled, no MFMA); 1x1 goes to the MFMA GEMM.  Returns 0 ok, <0 unsupported shape. */
 int mid_conv_fwd(mid_stream s, mid_workspace *ws, const float *x, const float *w, float *y, int N, int C, int H, int K,
                  int k, int stride);
+/* Batch-norm statistics fused into the producing convolution: when the layer runs on the implicit-GEMM kernel every
+ * workgroup also writes per-channel (count, mean, M2) partials of its output tile into parts->buf (three planes of
+ * [nparts][K]); parts->nparts comes back > 0.  0 = not fused: run the separate statistics pass (mid_bn_fwd). */
+typedef struct {
+    float *buf;
+    size_t floats;
+    int nparts;
+} mid_bn_parts;
+size_t mid_bn_parts_floats(int N, int K, int Ho);
+int mid_conv_fwd_stats(mid_stream s, mid_workspace *ws, const float *x, const float *w, float *y, int N, int C, int H, int K,
+                       int k, int stride, mid_bn_parts *parts);
 /* dx = dgrad (+ addend when addend != NULL; addend may alias dx) */
 int mid_conv_dgrad(mid_stream s, mid_workspace *ws, const float *w, const float *dy, float *dx, const float *addend,
                    int N, int C, int H, int K, int k, int stride);
@@ -85,6 +96,10 @@ size_t mid_bn_ws_floats(int C);
 int mid_bn_fwd(mid_stream s, float *stats_ws, const float *x, const float *gamma, const float *beta,
                const float *residual, float *means, float *vars, float *y, float *xhat_out, float *norm_out, int N,
                int C, int P, float eps, int relu);
+/* the same with the statistics taken from the partials a convolution left (parts->nparts > 0), else from x */
+int mid_bn_fwd_parts(mid_stream s, float *stats_ws, const mid_bn_parts *parts, const float *x, const float *gamma,
+                     const float *beta, const float *residual, float *means, float *vars, float *y, float *xhat_out,
+                     float *norm_out, int N, int C, int P, float eps, int relu);
 /* mask_mode 0 none; 1 recompute own ReLU mask from x; 2 gate dy by mask_src > 0 */
 int mid_bn_bwd(mid_stream s, float *stats_ws, const float *x, const float *gamma, const float *beta,
                const float *means, const float *vars, const float *dy, const float *mask_src, float *dx,

@@ -45,6 +45,8 @@ void mi_batch_ext_free(Batch *b);
 typedef struct MiCtx {
     mid_workspace ws;
     float *bn_ws;
+    mid_bn_parts bn_parts; /* statistics partials a forward convolution leaves for its batch norm */
+    int fuse_bn_stats;
     int *nan_flag_dev, *nan_flag_host;
     int full_store, dump_every, input_reset;
     char *dump_root;

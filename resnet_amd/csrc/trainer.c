@@ -302,6 +302,20 @@ static void size_workspaces(MiCtx *c, const Dims *d, ConvBlock **blocks, int N) 
     c->ws.wt = wt ? falloc(c, wt) : NULL;
     c->ws.part = part ? falloc(c, part) : NULL;
     c->bn_ws = falloc(c, mid_bn_ws_floats(maxc));
+    {
+        size_t pf = 0; /* largest statistics-partials table of any conv + BN unit */
+        for (int i = 0; i < d->n_conv_blocks; i++) {
+            const ConvBlock *b = blocks[i];
+            const int H = b->incoming_spatial_dim, Ho = H / b->stride;
+            size_t a = mid_bn_parts_floats(N, b->reduced_depth, H), e = mid_bn_parts_floats(N, b->expanded_depth, Ho);
+            if (a > pf) pf = a;
+            if (e > pf) pf = e;
+        }
+        c->bn_parts.floats = pf;
+        c->bn_parts.buf = pf ? falloc(c, pf) : NULL;
+        c->bn_parts.nparts = 0;
+        c->fuse_bn_stats = getenv("RESNET_MI_BNFUSE") ? atoi(getenv("RESNET_MI_BNFUSE")) : 1;
+    }
 }
 
 /* resnet.cu:1157-1194 */
@@ -428,9 +442,10 @@ static void unit_fwd(Train_ResNet *t, const float *in, const float *w, const Bat
                      int relu) {
     MiCtx *c = ctx_of(t);
     const int N = t->batch_size, Ho = H / stride;
-    mid_conv_fwd(G.compute, &c->ws, in, w, conv_out, N, C, H, K, k, stride);
-    mid_bn_fwd(G.compute, c->bn_ws, conv_out, bn->gamma, bn->beta, residual, cache->means, cache->vars, act_out,
-               cache->normalized_temp, cache->normalized, N, K, Ho * Ho, t->eps, relu);
+    /* the convolution leaves per-tile (count, mean, M2) partials of its output: BN reads the tensor twice, not three times */
+    mid_conv_fwd_stats(G.compute, &c->ws, in, w, conv_out, N, C, H, K, k, stride, c->fuse_bn_stats ? &c->bn_parts : NULL);
+    mid_bn_fwd_parts(G.compute, c->bn_ws, c->fuse_bn_stats ? &c->bn_parts : NULL, conv_out, bn->gamma, bn->beta, residual,
+                     cache->means, cache->vars, act_out, cache->normalized_temp, cache->normalized, N, K, Ho * Ho, t->eps, relu);
 }
 
 /* resnet.cu:1526-1775 */

@@ -175,6 +175,35 @@ def test_wgrad_scheduling_modes_bit_identical(cfg):
                 assert np.array_equal(a, b)
 
 
+def test_fused_bn_statistics_match_separate_pass(tmp_path):
+    """RESNET_MI_BNFUSE (default 1): the forward implicit-GEMM convolutions leave per-tile (count, mean, M2) partials of
+    their output and batch norm merges those instead of reading the tensor a third time.  A child process per setting runs
+    forward + backward of the same batch through the 3-block net with a striding block (every conv + BN unit but the stem
+    takes the fused route); loss and every gradient tensor must agree to fp32 reduction-order noise.  (The 16-block
+    network is not used here: at small batch ANY change of summation order -- e.g. RESNET_MI_IGEMM_TAIL=0 -- moves its
+    gradients by ~2 % rel-L2; its yardstick is test_reference_resnet50_step_parity, which runs with the fused statistics.)"""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import numpy as np, synth; from resnet_amd import Trainer; "
+            "tr = Trainer(synth.C1S_DIMS, 8, seed=1236); tr.source_synthetic(1234, 1235, pool_batches=2); "
+            "tr.load_new_batch(); tr.forward(); l = tr.loss()[0]; tr.backward(); tr.check(); "
+            "np.savez(sys.argv[1], loss=np.float64(l), **{'g%%03d' %% i: tr.get('grads', i) for i in range(len(tr.sizes))}); tr.close()")
+    here = os.path.dirname(os.path.abspath(__file__))
+    outs = []
+    for fuse in ("1", "0"):
+        f = str(tmp_path / ("g%s.npz" % fuse))
+        r = subprocess.run([sys.executable, "-c", code % (os.path.dirname(here), here), f], env=dict(os.environ, RESNET_MI_BNFUSE=fuse),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(f))
+    a, b = outs
+    assert np.isfinite(a["loss"]) and abs(a["loss"] - b["loss"]) <= 1e-5 * abs(b["loss"])
+    for k in b.files:
+        if k != "loss":
+            assert rel_l2(a[k], b[k]) <= 5 * GRAD_REL_L2, k
+
+
 def test_weight_init_matches_stream():
     from resnet_amd import Trainer
     dims = synth.C1_DIMS
