@@ -88,6 +88,12 @@ __device__ __forceinline__ void ig_merge(float &na, float &ma, float &qa, float 
 }
 
 #define IG_BK 32
+#ifdef IG_STAMP /* diagnostic build only (tools/variant.sh): per-workgroup s_memtime stamps of the kernel's phases */
+__device__ unsigned long long ig_stamps[8 * 16384];
+#define IG_T(slot) do { if (threadIdx.x == 0 && blockIdx.x < 16384 && blockIdx.y == 0) ig_stamps[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define IG_T(slot) do { } while (0)
+#endif
 #ifndef IG_ABLATE
 #define IG_ABLATE 0 /* experiments only: 1 = no staging after the first tile, 4 = no global loads */
 #endif
@@ -114,6 +120,7 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = WMW == 2 ? wave >> 1 : 0, wn = WMW == 2 ? wave & 1 : wave;
 
+    IG_T(0);
     // ---- block -> tile (XCD-contiguous, M-tiles fastest); blocks past g.full are reduction slices of the last tiles ----
     uint32_t L = blockIdx.x;
     int tail_id = -1, it0 = 0, nt_slice = 0;
@@ -222,7 +229,7 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
     auto ldg4 = [](const char *ubase, uint32_t lane_off) -> pf4 { return *(const pf4 *)(ubase + lane_off); };
 
     // Staging is cut into 8 parts so that it can be spread over the 16 MFMA groups of a tile.
-    auto fetch_part = [&](const int p) {
+    auto fetch_into = [&](const int p, pf4 *ra4, float *ra, float *rb, pf4 *rb4, int &sel_a, int &sel_b) {
         if (MODE == IG_FWD || MODE == IG_DGRAD) {
             if (p == 0) {
                 // past the last tile (the two drain iterations fetch unconditionally) the last tap is simply read again
@@ -290,7 +297,8 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
             rb[2 * p + 1] = ldg(fb + (size_t)(16 * p + 8) * g.HW * 4, fb_lane);
         }
     };
-    auto stash_part = [&](const int buf, const int p) {
+    auto fetch_part = [&](const int p) { fetch_into(p, ra4, ra, rb, rb4, sel_a, sel_b); };
+    auto stash_from = [&](const int buf, const int p, const pf4 *ra4, const float *ra, const float *rb, const pf4 *rb4, const int sel_a, const int sel_b) {
         float *as = As + buf * IG_BK * LDA, *bs = Bs + buf * IG_BK * LDB;
         if (MODE == IG_WGRAD) {
             const int kx = tid & 31, row = tid >> 5;
@@ -317,14 +325,22 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
             }
         }
     };
+    auto stash_part = [&](const int buf, const int p) { stash_from(buf, p, ra4, ra, rb, rb4, sel_a, sel_b); };
 
     const int fr = lane & 31, fk = lane >> 5;
+    {
+        // Prologue: tiles 0 and 1 are fetched back to back into two register sets (one memory latency, not two in a row);
+        // tile 0 goes to LDS from the temporary set, tile 1 stays in the loop's registers.
+        pf4 pa4[NA4], pb4[4];
+        float pa[NAS], pb[16];
+        int psel_a = 1, psel_b = 1;
 #pragma unroll
-    for (int p = 0; p < 8; p++) fetch_part(p);
+        for (int p = 0; p < 8; p++) fetch_into(p, pa4, pa, pb, pb4, psel_a, psel_b);
 #pragma unroll
-    for (int p = 0; p < 8; p++) stash_part(0, p);
+        for (int p = 0; p < 8; p++) fetch_part(p);
 #pragma unroll
-    for (int p = 0; p < 8; p++) fetch_part(p);
+        for (int p = 0; p < 8; p++) stash_from(0, p, pa4, pa, pb, pb4, psel_a, psel_b);
+    }
     // The loop is entered with NO load in flight: every register of tile 1 passes through an empty asm, so the compiler
     // drains vmcnt here, once (header note 2).
     if (MODE == IG_WGRAD) {
@@ -339,6 +355,7 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
 #pragma unroll
     for (int q = 0; q < 4; q++) { if (VB) asm volatile("" : "+v"(rb4[q])); }
     __syncthreads();
+    IG_T(1);
     for (int it = 0; it < ntiles; it++) {
         const int buf = it & 1;
         // The registers hold tile it+1: it goes to the other buffer, then the registers are refilled with tile it+2.
@@ -374,6 +391,7 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
         __syncthreads();
     }
 
+    IG_T(2);
     // ---- epilogue: accumulator layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) ----
     if (MODE != IG_WGRAD && tail_id >= 0) {
         float *tb = g.tailbuf + (size_t)tail_id * (BM * 128);
@@ -428,6 +446,7 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
         }
     }
 
+    IG_T(3);
     // ---- forward: batch-norm statistics of this tile (the separate read of the whole output is gone) ----
     // Each wave transposes its 64 x WNC accumulator tile through LDS (16-byte stores, XOR-swizzled: conflict-free both ways)
     // so that lane = row; the lane then walks its row's WNC values alone -- no cross-lane traffic (a butterfly per row cost
@@ -467,6 +486,7 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
         g.bn_part[plane + o] = nv > 0 ? s0 + sd * inv : 0.f;
         g.bn_part[2 * plane + o] = fmaxf(sq - sd * sd * inv, 0.f);
     }
+    IG_T(4);
 }
 
 // Sum of the reduction slices of the tail tiles, in slice order (deterministic), written where the tile's own epilogue
@@ -800,3 +820,9 @@ int mi_igemm_wgrad(hipStream_t st, mid_workspace *ws, const float *x, const floa
     MI_LAUNCH_CHECK("igemm_wgrad_reduce_kernel");
     return 0;
 }
+
+#ifdef IG_STAMP
+extern "C" int mi_debug_igemm_stamps(unsigned long long *dst, int nblocks) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(ig_stamps), sizeof(unsigned long long) * 8 * (size_t)nblocks) == hipSuccess ? 0 : -1;
+}
+#endif
