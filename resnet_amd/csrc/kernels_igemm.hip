@@ -586,6 +586,17 @@ igemm_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw
     for (int t = 0; t < T; t++) dw[i * T + t] = s[t];
 }
 
+// dW[k][c] = sum_z part[z][c][k] (1x1, transposed product)
+__global__ void __launch_bounds__(256)
+igemm_wgrad_reduce_t_kernel(const float *__restrict__ part, float *__restrict__ dw, int K, int C, int splits) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x; // over [c][k]: coalesced reads
+    if (i >= (long)K * C) return;
+    float s = 0.f;
+    for (int z = 0; z < splits; z++) s += part[(long)z * K * C + i];
+    const int c = (int)(i / K), kk = (int)(i - (long)c * K);
+    dw[(long)kk * C + c] = s;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 static int igemm_mode(void) {
     static int on = -1;
@@ -612,7 +623,8 @@ int mi_igemm_supported(int op, int N, int C, int H, int K, int k, int stride) {
     if ((double)N * C * H * H >= 1073741824.0 || (double)N * K * (H / stride) * (H / stride) >= 1073741824.0) return 0; /* 32-bit byte offsets */
     if (op == IGOP_FWD) return C % 32 == 0 && K % 64 == 0;
     if (op == IGOP_DGRAD) return K % 32 == 0 && C % 64 == 0;
-    return C % 128 == 0 && K % 64 == 0;
+    if (C % 128 == 0 && K % 64 == 0) return 1;
+    return k == 1 && C % 64 == 0 && K % 128 == 0; // 1x1 with 64 input channels: computed as the transposed product (below)
 }
 static int igemm_wgrad_splits(int N, int C, int H, int K, int k, int stride) {
     const int bm = K % 128 == 0 ? 128 : 64;
@@ -629,7 +641,11 @@ static int igemm_wgrad_splits(int N, int C, int H, int K, int k, int stride) {
     }
     return best;
 }
+// 1x1 weight gradient with C % 128 != 0 (the 64-channel layers): dW^T[c][k] = sum X[c] dY[k] -- the same kernel with the two
+// tensors in each other's role (rows = the 64 input channels as a 64-row tile, columns = output channels)
+static bool igemm_wgrad_swapped(int C, int K, int k) { return k == 1 && C % 128 != 0; }
 size_t mi_igemm_part_floats(int N, int C, int H, int K, int k, int stride) {
+    if (igemm_wgrad_swapped(C, K, k)) return (size_t)igemm_wgrad_splits(N, K, H, C, k, stride) * K * C;
     return (size_t)igemm_wgrad_splits(N, C, H, K, k, stride) * k * k * K * C;
 }
 
@@ -794,6 +810,29 @@ int mi_igemm_dgrad(hipStream_t st, mid_workspace *ws, const float *w, const floa
 
 int mi_igemm_wgrad(hipStream_t st, mid_workspace *ws, const float *x, const float *dy, float *dw, int N, int C, int H, int K, int k,
                    int stride) {
+    if (igemm_wgrad_swapped(C, K, k)) {
+        const int splits = igemm_wgrad_splits(N, K, H, C, 1, 1);
+        if (!ws || ws->part_floats < (size_t)splits * K * C) { mi_record_error("mi_igemm_wgrad", "workspace too small"); return -3; }
+        IgArgs g = {};
+        igemm_geometry(g, N, /*columns:*/ K, H, /*rows:*/ C, 1);
+        const int bm = C % 128 == 0 ? 128 : 64;
+        g.mtiles = C / bm;
+        g.ctiles = K / 128;
+        g.tiles = g.mtiles * g.ctiles;
+        g.fdM = make_fastdiv(g.mtiles);
+        const int kd = N * g.P;
+        g.full = g.tiles; g.tsplit = 1; g.fdTs = make_fastdiv(1); g.cpt = 1; g.fdCpt = make_fastdiv(1);
+        g.klen = mi_cdiv(mi_cdiv(kd, splits), IG_BK) * IG_BK;
+        const int used = mi_cdiv(kd, g.klen);
+        mi_prof_begin(st, igemm_fam(1), 2.0 * (double)kd * C * K, 4.0 * ((double)N * C * g.HW + (double)kd * K + (double)C * K));
+        const int rc = igemm_launch<IG_WGRAD>(st, dim3(g.tiles, used), /*rows from*/ x, /*columns from*/ dy, ws->part, nullptr, g, 1, 1, bm);
+        mi_prof_end(st);
+        if (rc) return rc;
+        MI_LAUNCH_CHECK("igemm_kernel<wgrad, transposed>");
+        hipLaunchKernelGGL(igemm_wgrad_reduce_t_kernel, dim3(mi_cdiv((long)K * C, 256)), dim3(256), 0, st, ws->part, dw, K, C, used);
+        MI_LAUNCH_CHECK("igemm_wgrad_reduce_t_kernel");
+        return 0;
+    }
     const int T = k * k;
     const int splits = igemm_wgrad_splits(N, C, H, K, k, stride);
     if (!ws || ws->part_floats < (size_t)splits * T * K * C) { mi_record_error("mi_igemm_wgrad", "workspace too small"); return -3; }
