@@ -113,6 +113,8 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
     // 1x1 forward / dgrad with Ho*Wo % 4 == 0: four consecutive columns are four consecutive pixels of one image, so the
     // B operand is staged with 16-byte loads / ds_write_b128 (4 per thread and k-step instead of 16 scalars)
     constexpr bool VB = VBP && KS == 1 && MODE != IG_WGRAD;
+    // wgrad with 64 input channels: a 128-column tile holds TWO taps x 64 channels (columns 0-63 tap 2*ct, 64-127 tap 2*ct+1)
+    constexpr bool CT64 = VBP && MODE == IG_WGRAD;
     extern __shared__ __attribute__((aligned(16))) float ig_smem[];
     float *As = ig_smem;                   // [2][32][LDA]
     float *Bs = ig_smem + 2 * IG_BK * LDA; // [2][32][LDB]
@@ -204,8 +206,11 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
             ntiles = ntaps * (g.K / IG_BK);
         }
     } else {
-        wg_t = (int)(ct / (uint32_t)g.ctiles);
-        cblk = (int)(ct - (uint32_t)wg_t * g.ctiles) * 128;
+        if (CT64) { wg_t = 2 * (int)ct; cblk = 0; }
+        else {
+            wg_t = (int)(ct / (uint32_t)g.ctiles);
+            cblk = (int)(ct - (uint32_t)wg_t * g.ctiles) * 128;
+        }
         wg_r = wg_t / KS; wg_s = wg_t - KS * wg_r;
         const int kbeg = (int)blockIdx.y * g.klen;
         kend = min(g.N * g.P, kbeg + g.klen);
@@ -225,6 +230,7 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
     int ld_k0 = (MODE == IG_WGRAD) ? (int)blockIdx.y * g.klen : 0;
     const char *fa = nullptr, *fb = nullptr; // wave-uniform bases of the tile being fetched (set by part 0)
     uint32_t fa_lane = 0, fb_lane = 0;       // per-lane byte offsets of the tile being fetched
+    uint32_t fb_lane2 = 0;                   // CT64: the second tap's offset (sel_b bit 1 = its validity)
     auto ldg = [](const char *ubase, uint32_t lane_off) -> float { return *(const float *)(ubase + lane_off); };
     auto ldg4 = [](const char *ubase, uint32_t lane_off) -> pf4 { return *(const pf4 *)(ubase + lane_off); };
 
@@ -287,14 +293,27 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
                 fa_lane = (n * (uint32_t)(g.K * g.P) + pp + row * g.P) * 4u;
                 const uint32_t pix = inb ? (uint32_t)(hi * g.W + wi) : (S * ho) * g.W + S * wo;
                 fb_lane = (n * (uint32_t)(g.C * g.HW) + pix + row * g.HW) * 4u;
+                if (CT64) {
+                    const int t1 = wg_t + 1, r1 = t1 / KS, s1 = t1 - KS * r1;
+                    const int hj = S * (int)ho - PAD + r1, wj = S * (int)wo - PAD + s1;
+                    const int inb1 = (int)((uint32_t)hj < (uint32_t)g.H) & (int)((uint32_t)wj < (uint32_t)g.W) & (int)(t1 < T);
+                    const uint32_t pix1 = inb1 ? (uint32_t)(hj * g.W + wj) : (S * ho) * g.W + S * wo;
+                    fb_lane2 = (n * (uint32_t)(g.C * g.HW) + pix1 + row * g.HW) * 4u;
+                    sel_b |= (sel_a & inb1) << 1;
+                }
                 ld_k0 += IG_BK;
             }
             if (NAS == 16) {
                 ra[2 * p] = ldg(fa + (size_t)(16 * p) * g.P * 4, fa_lane);
                 ra[2 * p + 1] = ldg(fa + (size_t)(16 * p + 8) * g.P * 4, fa_lane);
             } else ra[p] = ldg(fa + (size_t)(8 * p) * g.P * 4, fa_lane);
-            rb[2 * p] = ldg(fb + (size_t)(16 * p) * g.HW * 4, fb_lane);
-            rb[2 * p + 1] = ldg(fb + (size_t)(16 * p + 8) * g.HW * 4, fb_lane);
+            if (CT64) {
+                rb[2 * p] = ldg(fb + (size_t)(16 * (p & 3)) * g.HW * 4, p < 4 ? fb_lane : fb_lane2);
+                rb[2 * p + 1] = ldg(fb + (size_t)(16 * (p & 3) + 8) * g.HW * 4, p < 4 ? fb_lane : fb_lane2);
+            } else {
+                rb[2 * p] = ldg(fb + (size_t)(16 * p) * g.HW * 4, fb_lane);
+                rb[2 * p + 1] = ldg(fb + (size_t)(16 * p + 8) * g.HW * 4, fb_lane);
+            }
         }
     };
     auto fetch_part = [&](const int p) { fetch_into(p, ra4, ra, rb, rb4, sel_a, sel_b); };
@@ -306,8 +325,9 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
                 as[kx * LDA + row + 16 * p] = sel_a ? ra[2 * p] : 0.f;
                 as[kx * LDA + row + 16 * p + 8] = sel_a ? ra[2 * p + 1] : 0.f;
             } else as[kx * LDA + row + 8 * p] = sel_a ? ra[p] : 0.f;
-            bs[kx * LDB + row + 16 * p] = sel_b ? rb[2 * p] : 0.f;
-            bs[kx * LDB + row + 16 * p + 8] = sel_b ? rb[2 * p + 1] : 0.f;
+            const int sb = CT64 ? (sel_b >> (p >> 2)) & 1 : sel_b;
+            bs[kx * LDB + row + 16 * p] = sb ? rb[2 * p] : 0.f;
+            bs[kx * LDB + row + 16 * p + 8] = sb ? rb[2 * p + 1] : 0.f;
         } else {
             if (VB) {
                 if ((p & 1) == 0) {
@@ -410,8 +430,10 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
         size_t coff, rstride;
         bool cok;
         if (MODE == IG_WGRAD) {
-            cok = true;
-            coff = ((size_t)((size_t)blockIdx.y * T + wg_t) * g.K) * g.C + cblk + wn * WNC + j * 32 + (lane & 31);
+            const int lc = wn * WNC + j * 32 + (lane & 31);      // column of the tile
+            const int tap = CT64 ? wg_t + (lc >> 6) : wg_t;
+            cok = tap < T;
+            coff = ((size_t)((size_t)blockIdx.y * T + tap) * g.K) * g.C + (CT64 ? (lc & 63) : cblk + lc);
             rstride = (size_t)g.C;
         } else {
             cok = col < g.ncols;
@@ -624,11 +646,12 @@ int mi_igemm_supported(int op, int N, int C, int H, int K, int k, int stride) {
     if (op == IGOP_FWD) return C % 32 == 0 && K % 64 == 0;
     if (op == IGOP_DGRAD) return K % 32 == 0 && C % 64 == 0;
     if (C % 128 == 0 && K % 64 == 0) return 1;
+    if (k == 3 && C == 64 && K % 64 == 0) return 1;      // two taps per column tile (CT64)
     return k == 1 && C % 64 == 0 && K % 128 == 0; // 1x1 with 64 input channels: computed as the transposed product (below)
 }
 static int igemm_wgrad_splits(int N, int C, int H, int K, int k, int stride) {
     const int bm = K % 128 == 0 ? 128 : 64;
-    const long tiles = (long)k * k * (C / 128) * (K / bm);
+    const long tiles = (C == 64 && k == 3 ? 5L : (long)k * k * (C / 128)) * (K / bm);
     const long ksteps = ((long)N * (H / stride) * (H / stride) + IG_BK - 1) / IG_BK;
     const long slots = 512; // 256 CUs x 2 resident workgroups
     int best = 1;
@@ -737,6 +760,10 @@ static int igemm_launch(hipStream_t st, dim3 grid, const float *A, const float *
     if (MODE != IG_WGRAD && k == 1 && stride == 1 && g.P % 4 == 0)
         return bm == 128 ? igemm_launch_t<MODE, 1, 1, 2, true>(st, grid, A, B, out, addend, g)
                          : igemm_launch_t<MODE, 1, 1, 1, true>(st, grid, A, B, out, addend, g);
+    if (MODE == IG_WGRAD && k == 3 && g.C == 64) {
+        if (stride == 1) return bm == 128 ? igemm_launch_t<MODE, 3, 1, 2, true>(st, grid, A, B, out, addend, g) : igemm_launch_t<MODE, 3, 1, 1, true>(st, grid, A, B, out, addend, g);
+        return bm == 128 ? igemm_launch_t<MODE, 3, 2, 2, true>(st, grid, A, B, out, addend, g) : igemm_launch_t<MODE, 3, 2, 1, true>(st, grid, A, B, out, addend, g);
+    }
     IGL(1, 1) IGL(3, 1) IGL(3, 2)
 #undef IGL
     return -2;
@@ -841,7 +868,7 @@ int mi_igemm_wgrad(hipStream_t st, mid_workspace *ws, const float *x, const floa
     const int bm = K % 128 == 0 ? 128 : 64;
     g.mtiles = K / bm;
     g.ctiles = C / 128;
-    g.tiles = g.mtiles * T * g.ctiles;
+    g.tiles = C == 64 ? g.mtiles * ((T + 1) / 2) : g.mtiles * T * g.ctiles; // C == 64: two taps per column tile
     g.fdM = make_fastdiv(g.mtiles);
     const int kd = N * g.P;
     g.full = g.tiles; g.tsplit = 1; g.fdTs = make_fastdiv(1); g.cpt = 1; g.fdCpt = make_fastdiv(1);
