@@ -1,13 +1,12 @@
 // kernels_igemm.hip -- convolutions as an im2col-free implicit GEMM on the CDNA4 matrix cores, fp32
 // (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate).
 //
-// Which layers come here is a policy of mi_igemm_supported() (RESNET_MI_IGEMM, see there).  By default:
-//   * every 3x3 convolution whose channel counts tile, forward / dgrad / wgrad, stride 1 or 2 -- among them the reference's
-//     PROJECTION shortcuts, which are 3x3 / stride-2 / pad-1 (resnet.cu:884-889, 1693-1700), not the usual 1x1:
-//     256->512 @56, 512->1024 @28, 1024->2048 @14 hold 57% of the network's multiply-adds;
-//   * the weight gradients of the 1x1 convolutions.
-// The stem (C = 3), layers whose channels do not tile and, with RESNET_MI_IGEMM=1, the bottleneck's own 3x3 convolutions
-// run on the direct VALU kernels of kernels_conv.hip; 1x1 forward / dgrad on gemm_mfma_kernel.
+// Which layers come here is a policy of mi_igemm_supported() (RESNET_MI_IGEMM, see there).  By default every 3x3 and 1x1
+// convolution whose channel counts tile, forward / dgrad / wgrad -- among them the reference's PROJECTION shortcuts, which
+// are 3x3 / stride-2 / pad-1 (resnet.cu:884-889, 1693-1700), not the usual 1x1: 256->512 @56, 512->1024 @28,
+// 1024->2048 @14 hold 57% of the network's multiply-adds.  The stem (C = 3), shapes that do not tile and, with
+// RESNET_MI_IGEMM=1, the bottleneck's own 3x3 convolutions run on the direct VALU kernels of kernels_conv.hip; FC and
+// (RESNET_MI_IGEMM <= 1) 1x1 forward / dgrad on gemm_mfma_kernel.
 // The "im2col" matrix exists only as the 32 x 128 tile of LDS that the current k-step multiplies, gathered straight from
 // the NCHW tensor.
 //
@@ -18,10 +17,14 @@
 //            M = C, N = (n, pixel), reduction (tap,k); A = weights re-laid [t][k][c] (1x1: the KC tensor itself)
 //   wgrad    dW[k][c][t] = sum_{n,ho,wo} dY[n][k][ho][wo] X[n][c][S*ho-pad+r][S*wo-pad+s]
 //            M = K, N = (t,c), reduction (n,ho,wo) split over blockIdx.y; partials [split][t][k][c], reduced (and
-//            transposed to KCRS) by igemm_wgrad_reduce_kernel in a fixed order (deterministic)
+//            transposed to KCRS) by igemm_wgrad_reduce_kernel in a fixed order (deterministic).  64 input channels:
+//            3x3 with TWO taps per 128-column tile, 1x1 as the transposed product (rows = input channels)
+//   forward also leaves per-tile batch-norm statistics of its output (count, mean, M2 per channel and column group), so
+//   that BN does not read the tensor a third time (RESNET_MI_BNFUSE)
 //
 // Tile BM x 128 x 32 with BM = 128 (4 waves of 64x64) or 64 (4 waves of 64x32), 256 threads.  LDS double-buffered, one
-// barrier per k-step.  Staging is software-pipelined over the 16 MFMA groups of a k-step: the LDS stores of tile i+1 (held
+// barrier per k-step; tile height and a reduction-sliced last round chosen against workgroup-count quantisation
+// (igemm_pick_bm, igemm_tail_plan).  Staging is software-pipelined over the 16 MFMA groups of a k-step: the LDS stores of tile i+1 (held
 // in registers) ride with groups 0-7, the global loads of tile i+2 with groups 8-15.  What made this fast, in order of
 // effect (b7 projection wgrad 96 -> 117 TFLOP/s; MFMA-only ceiling of this loop 138):
 //   1. loads as `global_load v, v_off32, s[base]`: wave-uniform 64-bit base advanced on the scalar unit + 32-bit per-lane
