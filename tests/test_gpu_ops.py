@@ -231,7 +231,84 @@ def test_conv_parity_on_the_other_kernel_routes(mode):
     env = dict(os.environ, RESNET_MI_IGEMM=mode)
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_ops.py"), "-x", "-q", "-m", "gpu",
-                        "-k", "test_conv_fwd or test_conv_dgrad or test_conv_wgrad or unwritten_lds", "-p", "no:cacheprovider"],
+                        "-k", "test_conv_fwd or test_conv_dgrad or test_conv_wgrad or unwritten_lds or config2", "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(here))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def _basic_block(conv_fwd, conv_dgrad, conv_wgrad, bn_fwd, bn_bwd, x, w1, w2, g1, b1, g2, b2, up, eps=1e-7):
+    """ResNet-18 BasicBlock out = relu(bn2(conv2(relu(bn1(conv1(x))))) + x) and its backward, from the operator layer only
+    (3x3 conv forward / dgrad / wgrad + BN forward / backward: BASELINE.json configs[1]).  Arrays NHWC; the callables adapt
+    layouts.  Returns the tensors a trainer would keep."""
+    c1 = conv_fwd(x, w1)
+    m1, v1, a1 = bn_fwd(c1, g1, b1, 1, None)
+    c2 = conv_fwd(a1, w2)
+    m2, v2, out = bn_fwd(c2, g2, b2, 0, x)                   # + residual, ReLU
+    d_c2, dg2, db2 = bn_bwd(c2, g2, b2, m2, v2, up, 2, out)  # ReLU' of the block output as an external mask
+    dw2 = conv_wgrad(a1, d_c2)
+    d_a1 = conv_dgrad(w2, d_c2, None)
+    d_c1, dg1, db1 = bn_bwd(c1, g1, b1, m1, v1, d_a1, 1, None)
+    dw1 = conv_wgrad(x, d_c1)
+    shortcut = np.where(out > 0, up, 0).astype(np.float32)   # identity path: dL/dx += relu'(out) * up
+    dx = conv_dgrad(w1, d_c1, shortcut)
+    return dict(c1=c1, a1=a1, c2=c2, out=out, dw2=dw2, dg2=dg2, db2=db2, dw1=dw1, dg1=dg1, db1=db1, dx=dx)
+
+
+@pytest.mark.parametrize("C,H,N", [(64, 56, 8), (128, 28, 8), (256, 14, 16), (512, 7, 16)])
+def test_config2_resnet18_basic_block(ops, oracle, C, H, N):
+    """BASELINE.json configs[1] ("ResNet-18 ... 3x3 conv + BN kernels only"): the reference can only express bottleneck
+    nets, so a BasicBlock is composed from the C-ABI operators at the four ResNet-18 stage shapes and checked
+    against the same composition of oracle operators, forward and backward.  On the default route the 3x3 run on the MFMA
+    implicit GEMM; test_conv_parity_on_the_other_kernel_routes[0] pins the same operators on the MFMA-free direct kernels."""
+    eps = 1e-7
+    x = np.maximum(rand((N, H, H, C), 31), 0)  # a block input is post-ReLU
+    w1 = rand((C, C, 3, 3), 32, scale=(2.0 / (9 * 2 * C)) ** 0.5)
+    w2 = rand((C, C, 3, 3), 33, scale=(2.0 / (9 * 2 * C)) ** 0.5)
+    g1, g2 = (1 + 0.2 * rand((C,), 34)).astype(np.float32), (1 + 0.2 * rand((C,), 35)).astype(np.float32)
+    b1, b2 = (0.3 * rand((C,), 36)).astype(np.float32), (0.3 * rand((C,), 37)).astype(np.float32)
+    up = rand((N, H, H, C), 38)
+
+    def o_bn_fwd(t, g, b, relu, res):
+        m, v, xh, norm, act = oracle.bn_fwd(t, g, b, eps, relu)
+        return m, v, (np.maximum(act + res, 0) if res is not None else act)
+
+    def o_bn_bwd(t, g, b, m, v, dy, mode, mask):
+        _, _, xh, norm, act = oracle.bn_fwd(t, g, b, eps, 1 if mode == 1 else 0)
+        d = np.where(mask > 0, dy, 0).astype(np.float32) if mode == 2 else dy
+        return oracle.bn_bwd(t, g, eps, m, v, xh, act, d, 1 if mode == 1 else 0)
+
+    ref = _basic_block(lambda a, w: oracle.conv_fwd(a, w, 1), lambda w, d, add: oracle.conv_dgrad(w, d, H, 1, dx_init=add),
+                       lambda a, d: oracle.conv_wgrad(a, d, 3, 1), o_bn_fwd, o_bn_bwd, x, w1, w2, g1, b1, g2, b2, up)
+
+    def g_bn_fwd(t, g, b, relu, res):
+        m, v, y = ops.bn_fwd(nchw(t), g, b, eps, relu, residual=None if res is None else nchw(res))
+        return m, v, nhwc(y)
+
+    def g_bn_bwd(t, g, b, m, v, dy, mode, mask):
+        dx, dg, db = ops.bn_bwd(nchw(t), g, b, m, v, nchw(dy), eps, mode, mask_src=None if mask is None else nchw(mask))
+        return nhwc(dx), dg, db
+
+    # each GPU operator is fed the ORACLE's upstream tensors (op-by-op pinning: a ReLU gate that flips on a 1e-7 difference
+    # upstream would otherwise be charged to every operator downstream)
+    got = {}
+    got["c1"] = nhwc(ops.conv_fwd(nchw(x), w1, 1))
+    om1, ov1, _ = o_bn_fwd(ref["c1"], g1, b1, 1, None)
+    _, _, got["a1"] = g_bn_fwd(ref["c1"], g1, b1, 1, None)
+    got["c2"] = nhwc(ops.conv_fwd(nchw(ref["a1"]), w2, 1))
+    om2, ov2, _ = o_bn_fwd(ref["c2"], g2, b2, 0, x)
+    _, _, got["out"] = g_bn_fwd(ref["c2"], g2, b2, 0, x)
+    for k in ("c1", "a1", "c2", "out"):
+        check_act(got[k], ref[k], "BasicBlock %s" % k)
+    d_c2_ref, _, _ = o_bn_bwd(ref["c2"], g2, b2, om2, ov2, up, 2, ref["out"])
+    d_c2, dg2, db2 = g_bn_bwd(ref["c2"], g2, b2, om2, ov2, up, 2, ref["out"])
+    check_grad(d_c2, d_c2_ref, "BasicBlock d_c2"); check_grad(dg2, ref["dg2"], "dgamma2"); check_grad(db2, ref["db2"], "dbeta2")
+    check_grad(ops.conv_wgrad(nchw(ref["a1"]), nchw(d_c2_ref), 3, 1), ref["dw2"], "BasicBlock dw2")
+    d_a1_ref = oracle.conv_dgrad(w2, d_c2_ref, H, 1)
+    check_grad(nhwc(ops.conv_dgrad(w2, nchw(d_c2_ref), H, 1)), d_a1_ref, "BasicBlock d_a1")
+    d_c1_ref, _, _ = o_bn_bwd(ref["c1"], g1, b1, om1, ov1, d_a1_ref, 1, None)
+    d_c1, dg1, db1 = g_bn_bwd(ref["c1"], g1, b1, om1, ov1, d_a1_ref, 1, None)
+    check_grad(d_c1, d_c1_ref, "BasicBlock d_c1"); check_grad(dg1, ref["dg1"], "dgamma1"); check_grad(db1, ref["db1"], "dbeta1")
+    check_grad(ops.conv_wgrad(nchw(x), nchw(d_c1_ref), 3, 1), ref["dw1"], "BasicBlock dw1")
+    shortcut = np.where(ref["out"] > 0, up, 0).astype(np.float32)
+    check_grad(nhwc(ops.conv_dgrad(w1, nchw(d_c1_ref), H, 1, dx_init=nchw(shortcut))), ref["dx"], "BasicBlock dx (+shortcut)")
