@@ -29,7 +29,7 @@ FAMILIES = {0: "direct conv 7x7 stem / untiled 3x3 fwd+dgrad (dconv_kernel, VALU
 
 def cpu_baseline(seconds_budget=30.0):
     """The oracle (a CPU port: the reference has no CPU path) on a bounded sample of the same workload:
-    reference-defined ResNet-50, 224x224, fwd + bwd + Adam, batch 2, OpenMP over independent outputs."""
+    reference-defined ResNet-50, 224x224, fwd + bwd + Adam, batch 6, OpenMP over independent outputs."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import synth
     from oracle.oracle_py import Oracle, OracleNet
@@ -37,7 +37,7 @@ def cpu_baseline(seconds_budget=30.0):
     cores = min(cores, 32)
     o = Oracle("f32")
     o.set_threads(cores)
-    dims, batch = synth.R50_DIMS, 2
+    dims, batch = synth.R50_DIMS, 6  # ~10-15 s of CPU work on the GPU box's host cores
     net = OracleNet(o, dims, batch)
     params = synth.make_params(dims)
     for i, p in enumerate(params):

@@ -312,3 +312,28 @@ def test_config2_resnet18_basic_block(ops, oracle, C, H, N):
     check_grad(ops.conv_wgrad(nchw(x), nchw(d_c1_ref), 3, 1), ref["dw1"], "BasicBlock dw1")
     shortcut = np.where(ref["out"] > 0, up, 0).astype(np.float32)
     check_grad(nhwc(ops.conv_dgrad(w1, nchw(d_c1_ref), H, 1, dx_init=nchw(shortcut))), ref["dx"], "BasicBlock dx (+shortcut)")
+
+
+SWEEP = [
+    # (C, H, K, k, stride, N): ragged column counts, odd batches, every tile-height / tail-slice / two-tap / transposed route
+    (64, 10, 64, 3, 1, 3), (64, 10, 192, 3, 1, 5), (128, 12, 64, 3, 2, 7), (192, 6, 320, 3, 2, 9), (256, 4, 256, 3, 2, 33),
+    (96, 14, 128, 3, 1, 2), (64, 6, 128, 1, 1, 11), (64, 9, 256, 1, 1, 3), (320, 5, 64, 1, 1, 13), (128, 7, 1024, 1, 1, 6),
+    (1024, 3, 128, 1, 1, 17), (32, 8, 64, 3, 1, 4), (64, 8, 96, 3, 1, 2), (128, 2, 128, 3, 1, 3), (128, 16, 128, 3, 2, 1),
+    (512, 4, 512, 3, 1, 40), (64, 32, 64, 1, 1, 9),
+]
+
+
+@pytest.mark.parametrize("shape", SWEEP, ids=["C%d_H%d_K%d_k%d_s%d_N%d" % s for s in SWEEP])
+def test_conv_shape_sweep(ops, oracle, shape):
+    """shapes chosen to hit the planners' corners rather than the network's layers: column counts that are not multiples
+    of 128 (ragged last tile, with and without a sliced tail round), 64- and 128-row tiles, channel counts that tile for
+    one operator but not another (fallback to the direct / plain-GEMM kernels mid-layer), 2x2 and 3x3 images (every tap
+    out of the image somewhere), odd batches"""
+    C, H, K, k, stride, N = shape
+    x, w, dy = _conv_data(*shape, seed=11)
+    check_act(nhwc(ops.conv_fwd(nchw(x), w, stride)), oracle.conv_fwd(x, w, stride), "fwd %s" % (shape,))
+    base = rand((N, H, H, C), 98)
+    check_grad(nhwc(ops.conv_dgrad(w, nchw(dy), H, stride)), oracle.conv_dgrad(w, dy, H, stride), "dgrad %s" % (shape,))
+    check_grad(nhwc(ops.conv_dgrad(w, nchw(dy), H, stride, dx_init=nchw(base))), oracle.conv_dgrad(w, dy, H, stride, dx_init=base),
+               "dgrad+add %s" % (shape,))
+    check_grad(ops.conv_wgrad(nchw(x), nchw(dy), k, stride), oracle.conv_wgrad(x, dy, k, stride), "wgrad %s" % (shape,))
