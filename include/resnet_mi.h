@@ -290,6 +290,11 @@ int mi_op_bn_fwd_add_relu(const float *x, const float *gamma, const float *beta,
 int mi_op_bn_bwd(const float *x, const float *gamma, const float *beta, const float *means, const float *vars,
                  const float *dy, const float *mask_src, float *dx, float *dgamma, float *dbeta, int N, int C, int H,
                  float eps, int mask_mode);
+/* mask_mode 2 that also writes gated_out = (mask_src > 0 ? dy : 0): what backwards_pass uses for identity blocks, where the
+ * gated upstream gradient is needed again as the shortcut addend (doActivationDeriv, resnet.cu:1934, without its own pass) */
+int mi_op_bn_bwd_gate(const float *x, const float *gamma, const float *beta, const float *means, const float *vars,
+                      const float *dy, const float *mask_src, float *gated_out, float *dx, float *dgamma, float *dbeta, int N,
+                      int C, int H, float eps);
 int mi_op_maxpool_fwd(const float *x, float *y, int *max_inds, int N, int C, int H, int k, int stride);
 int mi_op_maxpool_bwd(const int *max_inds, const float *dy, float *dx, int N, int C, int H, int k, int stride);
 int mi_op_avgpool_fwd(const float *x, float *y, int N, int C, int H);

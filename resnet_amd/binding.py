@@ -153,6 +153,7 @@ PROTOTYPES = {
     "mi_op_bn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i]),
     "mi_op_bn_fwd_add_relu": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f]),
     "mi_op_bn_bwd": (_i, [_vp] * 10 + [_i, _i, _i, _f, _i]),
+    "mi_op_bn_bwd_gate": (_i, [_vp] * 11 + [_i, _i, _i, _f]),
     "mi_op_maxpool_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "mi_op_maxpool_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "mi_op_avgpool_fwd": (_i, [_vp, _vp, _i, _i, _i]),

@@ -214,56 +214,68 @@ bn_apply_kernel(const float *__restrict__ x, const float *__restrict__ gamma, co
 }
 
 // grid (C, nsplit): s1 = sum g, s2 = sum g * x_hat.  Same flattened (image, position) walk as bn_stats_kernel.
+// MASK 3 = MASK 2 (gate dy by mask_src > 0) that also WRITES the gated dy: the identity blocks need relu'(out) * upstream
+// twice more (BN' apply, shortcut addend of the 1x1 dgrad), and producing it here saves the separate ReLU' pass.
 template <int MASK, bool VEC>
 __global__ void __launch_bounds__(256)
 bn_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ mask_src,
                      const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ means,
-                     const float *__restrict__ vars, float *__restrict__ partial, int N, int C, int P, float eps, FastDiv fdPV) {
+                     const float *__restrict__ vars, float *__restrict__ partial, float *__restrict__ gated, int N, int C, int P,
+                     float eps, FastDiv fdPV) {
     const int c = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
     const float mean = means[c], sd = sqrtf(vars[c] + eps), g = gamma[c], b = beta[c];
     const int cnt = (N - split + nsplit - 1) / nsplit;
     constexpr int V = VEC ? 4 : 1;
+    constexpr bool EXT = MASK == 2 || MASK == 3;
     const uint32_t PV = (uint32_t)P / V;
     const uint32_t total = (uint32_t)cnt * PV;
     const size_t img_stride = (size_t)nsplit * C * P;
     const size_t base = ((size_t)split * C + c) * P;
     float s1 = 0.f, s2 = 0.f;
-    auto one = [&](float xv, float d, float m) {
+    auto one = [&](float xv, float d, float m) -> float {
         const float xh = bn_xhat(xv, mean, sd);
         bool on = true;
         if (MASK == 1) on = bn_y(xh, g, b) > 0.f;
-        if (MASK == 2) on = m > 0.f;
+        if (EXT) on = m > 0.f;
         if (on) { s1 += d; s2 = fmaf(d, xh, s2); }
+        return on ? d : 0.f;
     };
     auto off = [&](uint32_t idx) -> size_t {
         const uint32_t j = fd_div(idx, fdPV), i = idx - j * PV;
         return base + (size_t)j * img_stride + (size_t)i * V;
     };
-    constexpr int U = MASK == 2 ? 2 : 4; // loads in flight per thread: U x (2 or 3) x 16 B
+    constexpr int U = EXT ? 2 : 4; // loads in flight per thread: U x (2 or 3) x 16 B
     uint32_t idx = threadIdx.x;
     for (; idx + (U - 1) * 256 < total; idx += U * 256) {
         if (VEC) {
             float4 xv[U], dv[U], mv[U];
+            size_t o[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const size_t o = off(idx + u * 256);
-                xv[u] = *(const float4 *)(x + o); dv[u] = *(const float4 *)(dy + o);
-                if (MASK == 2) mv[u] = *(const float4 *)(mask_src + o); else mv[u] = make_float4(1.f, 1.f, 1.f, 1.f);
+                o[u] = off(idx + u * 256);
+                xv[u] = *(const float4 *)(x + o[u]); dv[u] = *(const float4 *)(dy + o[u]);
+                if (EXT) mv[u] = *(const float4 *)(mask_src + o[u]); else mv[u] = make_float4(1.f, 1.f, 1.f, 1.f);
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                one(xv[u].x, dv[u].x, mv[u].x); one(xv[u].y, dv[u].y, mv[u].y);
-                one(xv[u].z, dv[u].z, mv[u].z); one(xv[u].w, dv[u].w, mv[u].w);
+                float4 gq;
+                gq.x = one(xv[u].x, dv[u].x, mv[u].x); gq.y = one(xv[u].y, dv[u].y, mv[u].y);
+                gq.z = one(xv[u].z, dv[u].z, mv[u].z); gq.w = one(xv[u].w, dv[u].w, mv[u].w);
+                if (MASK == 3) *(float4 *)(gated + o[u]) = gq;
             }
         } else {
             float xv[U], dv[U], mv[U];
+            size_t o[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const size_t o = off(idx + u * 256);
-                xv[u] = x[o]; dv[u] = dy[o]; mv[u] = MASK == 2 ? mask_src[o] : 1.f;
+                o[u] = off(idx + u * 256);
+                xv[u] = x[o[u]]; dv[u] = dy[o[u]]; mv[u] = EXT ? mask_src[o[u]] : 1.f;
             }
 #pragma unroll
-            for (int u = 0; u < U; u++) one(xv[u], dv[u], mv[u]);
+            for (int u = 0; u < U; u++) {
+                const float gq = one(xv[u], dv[u], mv[u]);
+                if (MASK == 3) gated[o[u]] = gq;
+            }
         }
     }
     for (; idx < total; idx += 256) {
@@ -271,9 +283,14 @@ bn_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ dy, 
         if (VEC) {
             const float4 xv = *(const float4 *)(x + o), dv = *(const float4 *)(dy + o);
             float4 mv = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (MASK == 2) mv = *(const float4 *)(mask_src + o);
-            one(xv.x, dv.x, mv.x); one(xv.y, dv.y, mv.y); one(xv.z, dv.z, mv.z); one(xv.w, dv.w, mv.w);
-        } else one(x[o], dy[o], MASK == 2 ? mask_src[o] : 1.f);
+            if (EXT) mv = *(const float4 *)(mask_src + o);
+            float4 gq;
+            gq.x = one(xv.x, dv.x, mv.x); gq.y = one(xv.y, dv.y, mv.y); gq.z = one(xv.z, dv.z, mv.z); gq.w = one(xv.w, dv.w, mv.w);
+            if (MASK == 3) *(float4 *)(gated + o) = gq;
+        } else {
+            const float gq = one(x[o], dy[o], EXT ? mask_src[o] : 1.f);
+            if (MASK == 3) gated[o] = gq;
+        }
     }
     s1 = wave_sum(s1); s2 = wave_sum(s2);
     __shared__ float sh[8];
@@ -406,20 +423,22 @@ int mid_bn_fwd_parts(mid_stream s, float *ws, const mid_bn_parts *parts, const f
     return rc;
 }
 
-int mid_bn_bwd(mid_stream s, float *ws, const float *x, const float *gamma, const float *beta, const float *means,
-               const float *vars, const float *dy, const float *mask_src, float *dx, float *dgamma, float *dbeta, int N,
-               int C, int P, float eps, int mask_mode) {
-    hipStream_t st = (hipStream_t)s;
+static int bn_bwd_impl(hipStream_t st, float *ws, const float *x, const float *gamma, const float *beta, const float *means,
+                       const float *vars, const float *dy, const float *mask_src, float *gated_out, float *dx, float *dgamma,
+                       float *dbeta, int N, int C, int P, float eps, int mask_mode) {
     const int ns = bn_nsplit(N, C);
     dim3 grid(C, ns), block(256);
-    if (mask_mode == 2 && !mask_src) { mi_record_error("mid_bn_bwd", "mask_src missing"); return -2; }
-    mi_prof_begin(st, MI_FAM_BN, 0.0, 4.0 * (double)N * C * P * (mask_mode == 2 ? 7 : 5));
+    if (mask_mode >= 2 && !mask_src) { mi_record_error("mid_bn_bwd", "mask_src missing"); return -2; }
+    if (mask_mode == 3 && !gated_out) { mi_record_error("mid_bn_bwd_gate", "gated_out missing"); return -2; }
+    // passes over N*C*P floats: reduce reads x, dy (+mask) (+writes gated); apply reads x, dy (+mask) | x, gated; writes dx
+    mi_prof_begin(st, MI_FAM_BN, 0.0, 4.0 * (double)N * C * P * (mask_mode == 2 ? 7 : mask_mode == 3 ? 7 : 5));
     const bool rvec = (P & 3) == 0;
     const FastDiv fdPV = make_fastdiv(rvec ? P / 4 : P);
-#define BWD_REDUCE(M_, V_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<M_, V_>), grid, block, 0, st, x, dy, mask_src, gamma, beta, means, vars, ws, N, C, P, eps, fdPV)
+#define BWD_REDUCE(M_, V_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<M_, V_>), grid, block, 0, st, x, dy, mask_src, gamma, beta, means, vars, ws, gated_out, N, C, P, eps, fdPV)
     if (mask_mode == 0) { if (rvec) BWD_REDUCE(0, true); else BWD_REDUCE(0, false); }
     else if (mask_mode == 1) { if (rvec) BWD_REDUCE(1, true); else BWD_REDUCE(1, false); }
-    else { if (rvec) BWD_REDUCE(2, true); else BWD_REDUCE(2, false); }
+    else if (mask_mode == 2) { if (rvec) BWD_REDUCE(2, true); else BWD_REDUCE(2, false); }
+    else { if (rvec) BWD_REDUCE(3, true); else BWD_REDUCE(3, false); }
 #undef BWD_REDUCE
     MI_LAUNCH_CHECK("bn_bwd_reduce_kernel");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(mi_cdiv(C, 64)), dim3(64), 0, st, ws, ns, C, dgamma, dbeta);
@@ -429,15 +448,28 @@ int mid_bn_bwd(mid_stream s, float *ws, const float *x, const float *gamma, cons
     const float inv_m = 1.0f / (float)((size_t)N * P);
     const bool vec = (P & 3) == 0;
     dim3 g2(ew_blocks(vec ? total / 4 : total));
-#define BWD_APPLY(M_, V_)                                                                                          \
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<M_, V_>), g2, block, 0, st, x, dy, mask_src, gamma, beta, means, vars, \
+    const float *dy_apply = mask_mode == 3 ? gated_out : dy; // mode 3: the gated dy is already there, no mask needed
+#define BWD_APPLY(M_, V_)                                                                                                \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<M_, V_>), g2, block, 0, st, x, dy_apply, mask_src, gamma, beta, means, vars, \
                        dgamma, dbeta, dx, C, P, fdP, fdC, total, inv_m, eps)
-    if (mask_mode == 0) { if (vec) BWD_APPLY(0, true); else BWD_APPLY(0, false); }
+    if (mask_mode == 0 || mask_mode == 3) { if (vec) BWD_APPLY(0, true); else BWD_APPLY(0, false); }
     else if (mask_mode == 1) { if (vec) BWD_APPLY(1, true); else BWD_APPLY(1, false); }
     else { if (vec) BWD_APPLY(2, true); else BWD_APPLY(2, false); }
 #undef BWD_APPLY
     mi_prof_end(st);
     MI_LAUNCH_CHECK("bn_bwd_apply_kernel");
     return 0;
+}
+
+int mid_bn_bwd(mid_stream s, float *ws, const float *x, const float *gamma, const float *beta, const float *means,
+               const float *vars, const float *dy, const float *mask_src, float *dx, float *dgamma, float *dbeta, int N,
+               int C, int P, float eps, int mask_mode) {
+    if (mask_mode < 0 || mask_mode > 2) { mi_record_error("mid_bn_bwd", "mask_mode"); return -2; }
+    return bn_bwd_impl((hipStream_t)s, ws, x, gamma, beta, means, vars, dy, mask_src, nullptr, dx, dgamma, dbeta, N, C, P, eps, mask_mode);
+}
+int mid_bn_bwd_gate(mid_stream s, float *ws, const float *x, const float *gamma, const float *beta, const float *means,
+                    const float *vars, const float *dy, const float *mask_src, float *gated_out, float *dx, float *dgamma,
+                    float *dbeta, int N, int C, int P, float eps) {
+    return bn_bwd_impl((hipStream_t)s, ws, x, gamma, beta, means, vars, dy, mask_src, gated_out, dx, dgamma, dbeta, N, C, P, eps, 3);
 }
 }

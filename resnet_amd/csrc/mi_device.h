@@ -105,6 +105,12 @@ int mid_bn_bwd(mid_stream s, float *stats_ws, const float *x, const float *gamma
                const float *means, const float *vars, const float *dy, const float *mask_src, float *dx,
                float *dgamma, float *dbeta, int N, int C, int P, float eps, int mask_mode);
 
+/* mask_mode 2 that also writes gated_out = (mask_src > 0 ? dy : 0), the tensor doActivationDeriv (resnet.cu:1934) would
+ * have produced in a pass of its own; gated_out may not alias dx */
+int mid_bn_bwd_gate(mid_stream s, float *stats_ws, const float *x, const float *gamma, const float *beta,
+                    const float *means, const float *vars, const float *dy, const float *mask_src, float *gated_out,
+                    float *dx, float *dgamma, float *dbeta, int N, int C, int P, float eps);
+
 /* ---- pools, elementwise, loss, optimizer ---- */
 int mid_maxpool_fwd(mid_stream s, const float *x, float *y, int *max_inds, int N, int C, int H, int k, int stride);
 int mid_maxpool_bwd(mid_stream s, const int *max_inds, const float *dy, float *dx, int N, int C, int H, int k,

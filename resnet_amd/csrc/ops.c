@@ -66,6 +66,14 @@ int mi_op_bn_bwd(const float *x, const float *gamma, const float *beta, const fl
     mid_free(ws);
     return rc;
 }
+int mi_op_bn_bwd_gate(const float *x, const float *gamma, const float *beta, const float *means, const float *vars,
+                      const float *dy, const float *mask_src, float *gated_out, float *dx, float *dgamma, float *dbeta, int N,
+                      int C, int H, float eps) {
+    float *ws = (float *)mid_malloc(mid_bn_ws_floats(C) * sizeof(float));
+    int rc = finish(mid_bn_bwd_gate(mi_global()->compute, ws, x, gamma, beta, means, vars, dy, mask_src, gated_out, dx, dgamma, dbeta, N, C, H * H, eps));
+    mid_free(ws);
+    return rc;
+}
 int mi_op_maxpool_fwd(const float *x, float *y, int *max_inds, int N, int C, int H, int k, int stride) {
     return finish(mid_maxpool_fwd(mi_global()->compute, x, y, max_inds, N, C, H, k, stride));
 }

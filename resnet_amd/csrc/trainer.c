@@ -532,13 +532,17 @@ static float *ring_take(MiCtx *c, int *slot) {
 /* d_slot: ring slot holding d_conv_out (mode 2), -1 otherwise */
 static void unit_bwd(Train_ResNet *t, const float *in, const float *w, const BatchNorm *bn, const Cache_BatchNorm *cache,
                      const BatchNorm *dbn, const float *conv_out, const float *dy, const float *mask_src, int mask_mode,
-                     float *d_conv_out, int d_slot, float *dx, const float *addend, float *dw, int C, int H, int K, int k,
+                     float *gated_out, float *d_conv_out, int d_slot, float *dx, const float *addend, float *dw, int C, int H, int K, int k,
                      int stride) {
     MiCtx *c = ctx_of(t);
     const int N = t->batch_size, Ho = H / stride;
     /* BN' of this unit (HBM-bound) runs next to earlier units' weight gradients (FMA-bound, low-priority aux stream) */
-    mid_bn_bwd(G.compute, c->bn_ws, conv_out, bn->gamma, bn->beta, cache->means, cache->vars, dy, mask_src, d_conv_out,
-               dbn->gamma, dbn->beta, N, K, Ho * Ho, t->eps, mask_mode);
+    if (mask_mode == 3) /* ReLU' of the block output fused in, and its product with the upstream gradient kept (gated_out) */
+        mid_bn_bwd_gate(G.compute, c->bn_ws, conv_out, bn->gamma, bn->beta, cache->means, cache->vars, dy, mask_src, gated_out,
+                        d_conv_out, dbn->gamma, dbn->beta, N, K, Ho * Ho, t->eps);
+    else
+        mid_bn_bwd(G.compute, c->bn_ws, conv_out, bn->gamma, bn->beta, cache->means, cache->vars, dy, mask_src, d_conv_out,
+                   dbn->gamma, dbn->beta, N, K, Ho * Ho, t->eps, mask_mode);
     if (c->overlap_wgrad == 2 && d_slot >= 0) {
         /* d_conv_out is final once BN' is: the weight gradient may start now and run for as long as the slot lives */
         mid_event_record(c->ev_bn_done, G.compute);
@@ -601,27 +605,28 @@ void backwards_pass(Train_ResNet *t) {
         if (b->projection) {
             /* ReLU' of the block output is fused into both BN' as an external mask (doActivationDeriv, :1934) */
             unit_bwd(t, bin, b->projection, b->norm_projection, k->norm_post_projection, db->norm_projection,
-                     k->transformed_residual, up, k->output_activated, 2, dk->transformed_residual, s_proj, dbin, NULL,
+                     k->transformed_residual, up, k->output_activated, 2, NULL, dk->transformed_residual, s_proj, dbin, NULL,
                      db->projection, b->incoming_filters, H, b->expanded_depth, b->stride == 2 ? 3 : 1, b->stride);
             exp_dy = up; exp_mask = k->output_activated; exp_mode = 2;
             red_addend = dbin; /* reduce-conv dgrad accumulates onto the projection path (toAdd, :2157) */
         } else {
-            mid_relu_deriv(G.compute, k->output_activated, up, dk->output, (size_t)N * b->expanded_depth * Ho * Ho);
-            exp_dy = dk->output; exp_mask = NULL; exp_mode = 0;
+            /* doActivationDeriv (:1934) rides in the expansion BN' reduce pass, which also leaves relu'(out) * up in dk->output
+             * (one pass over the block output less than a separate ReLU' kernel) */
+            exp_dy = up; exp_mask = k->output_activated; exp_mode = 3;
             red_addend = dk->output; /* identity shortcut: setVal 0 + addVec (:2003-2004) folded into the dgrad epilogue */
         }
         if (ring) { dk->post_expanded = ring_take(c, &s_exp); dk->post_spatial_activated = ring_take(c, NULL); }
         unit_bwd(t, k->post_spatial_activated, b->depth_expansion, b->norm_expansion, k->norm_post_expanded,
-                 db->norm_expansion, k->post_expanded, exp_dy, exp_mask, exp_mode, dk->post_expanded, s_exp,
+                 db->norm_expansion, k->post_expanded, exp_dy, exp_mask, exp_mode, dk->output, dk->post_expanded, s_exp,
                  dk->post_spatial_activated, NULL, db->depth_expansion, b->reduced_depth, Ho, b->expanded_depth, 1, 1);
         /* the call resnet.cu:2060-2083 forgot; present in resnet_cudnn.cu:2365-2366 */
         if (ring) { dk->post_spatial = ring_take(c, &s_spa); dk->post_reduced_activated = ring_take(c, NULL); }
         unit_bwd(t, k->post_reduced_activated, b->spatial, b->norm_spatial, k->norm_post_spatial, db->norm_spatial,
-                 k->post_spatial, dk->post_spatial_activated, NULL, 1, dk->post_spatial, s_spa, dk->post_reduced_activated, NULL,
+                 k->post_spatial, dk->post_spatial_activated, NULL, 1, NULL, dk->post_spatial, s_spa, dk->post_reduced_activated, NULL,
                  db->spatial, b->reduced_depth, H, b->reduced_depth, 3, b->stride);
         if (ring) dk->post_reduced = ring_take(c, &s_red);
         unit_bwd(t, bin, b->depth_reduction, b->norm_depth_reduction, k->norm_post_reduced, db->norm_depth_reduction,
-                 k->post_reduced, dk->post_reduced_activated, NULL, 1, dk->post_reduced, s_red, dbin, red_addend,
+                 k->post_reduced, dk->post_reduced_activated, NULL, 1, NULL, dk->post_reduced, s_red, dbin, red_addend,
                  db->depth_reduction, b->incoming_filters, H, b->reduced_depth, 1, 1);
         mi_dp_reduce_ready(t, (size_t)(db->depth_reduction - c->g_arena), 0);
     }
@@ -631,7 +636,7 @@ void backwards_pass(Train_ResNet *t) {
     mid_maxpool_bwd(G.compute, a->max_inds, da->init_convblock_input, da->init_conv_activated, N, d->init_conv_filters, Hs,
                     d->init_maxpool_dim, d->init_maxpool_stride);
     unit_bwd(t, t->cur_batch->images, p->init_conv_layer, p->norm_init_conv, a->norm_init_conv, dp->norm_init_conv,
-             a->init_conv_applied, da->init_conv_activated, NULL, 1, da->init_conv_applied, s_stem, NULL, NULL,
+             a->init_conv_applied, da->init_conv_activated, NULL, 1, NULL, da->init_conv_applied, s_stem, NULL, NULL,
              dp->init_conv_layer, 3, d->input, d->init_conv_filters, d->init_kernel_dim, d->init_conv_stride);
     mi_dp_reduce_ready(t, 0, 1);
     mid_event_record(c->ev_t[3], G.compute);

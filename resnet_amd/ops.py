@@ -94,6 +94,15 @@ class Ops:
                                       out.ptr, ogam.ptr, obet.ptr, N, Cc, H, eps, mask_mode), "bn_bwd")
         return out.get(), ogam.get(), obet.get()
 
+    def bn_bwd_gate(self, x, gamma, beta, means, vars_, dy, eps, mask_src):
+        """BN backward with dy gated by mask_src > 0; also returns the gated dy (mi_op_bn_bwd_gate)"""
+        N, Cc, H, _ = x.shape
+        dx, dg, db, dm, dv, ddy, dmask = (self.dev(a) for a in (x, gamma, beta, means, vars_, dy, mask_src))
+        out, gated, ogam, obet = self.dev(shape=x.shape), self.dev(shape=x.shape), self.dev(shape=(Cc,)), self.dev(shape=(Cc,))
+        self._chk(self.L.mi_op_bn_bwd_gate(dx.ptr, dg.ptr, db.ptr, dm.ptr, dv.ptr, ddy.ptr, dmask.ptr, gated.ptr, out.ptr, ogam.ptr,
+                                           obet.ptr, N, Cc, H, eps), "bn_bwd_gate")
+        return out.get(), ogam.get(), obet.get(), gated.get()
+
     def maxpool_fwd(self, x, k, stride):
         N, Cc, H, _ = x.shape
         Ho = H // stride

@@ -136,6 +136,10 @@ def test_bn_add_relu_and_external_mask(ops, oracle, C, H, N):
     check_grad(gdb, rdb, "bn dbeta (external mask)")
     got = ops.relu_deriv(gy, nchw(up))
     assert np.array_equal(nhwc(got), d_sum)
+    # the variant backwards_pass uses for identity blocks: same gradients, plus the gated upstream gradient itself
+    hdx, hdg, hdb, gated = ops.bn_bwd_gate(nchw(x), gamma, beta, gm, gv, nchw(up), eps, gy)
+    assert np.array_equal(nhwc(gated), d_sum)
+    assert np.array_equal(hdx, gdx) and np.array_equal(hdg, gdg) and np.array_equal(hdb, gdb)
 
 
 @pytest.mark.parametrize("C,H,N", [(64, 112, 2), (64, 16, 4)])
