@@ -600,14 +600,16 @@ void backwards_pass(Train_ResNet *t) {
         const float *exp_dy, *exp_mask, *red_addend;
         int exp_mode, s_proj = -1, s_exp = -1, s_spa = -1, s_red = -1;
         if (ring) { /* this block's derivative tensors: fresh ring slots (resnet_cudnn_lowmem.cu:2152-2170 keeps four) */
-            if (b->projection) dk->transformed_residual = ring_take(c, &s_proj); else dk->output = ring_take(c, NULL);
+            dk->output = ring_take(c, NULL);
+            if (b->projection) dk->transformed_residual = ring_take(c, &s_proj);
         }
         if (b->projection) {
-            /* ReLU' of the block output is fused into both BN' as an external mask (doActivationDeriv, :1934) */
+            /* ReLU' of the block output (doActivationDeriv, :1934) is fused into the projection BN' as an external mask; that
+             * pass also leaves relu'(out) * up in dk->output, which the expansion BN' then reads instead of up + mask */
             unit_bwd(t, bin, b->projection, b->norm_projection, k->norm_post_projection, db->norm_projection,
-                     k->transformed_residual, up, k->output_activated, 2, NULL, dk->transformed_residual, s_proj, dbin, NULL,
+                     k->transformed_residual, up, k->output_activated, 3, dk->output, dk->transformed_residual, s_proj, dbin, NULL,
                      db->projection, b->incoming_filters, H, b->expanded_depth, b->stride == 2 ? 3 : 1, b->stride);
-            exp_dy = up; exp_mask = k->output_activated; exp_mode = 2;
+            exp_dy = dk->output; exp_mask = NULL; exp_mode = 0;
             red_addend = dbin; /* reduce-conv dgrad accumulates onto the projection path (toAdd, :2157) */
         } else {
             /* doActivationDeriv (:1934) rides in the expansion BN' reduce pass, which also leaves relu'(out) * up in dk->output
