@@ -675,8 +675,9 @@ size_t mi_igemm_part_floats(int N, int C, int H, int K, int k, int stride) {
     return (size_t)igemm_wgrad_splits(N, C, H, K, k, stride) * k * k * K * C;
 }
 
-#define IG_SLOTS 512              /* 256 CUs x 2 resident workgroups */
-#define IG_TAIL_FLOATS ((size_t)IG_SLOTS * 128 * 128) /* partial-tile buffer: one slice per slot, 33.5 MB */
+#define IG_SLOTS 512              /* 256 CUs x 2 resident workgroups of 128-row tiles (67.6 KB of LDS each) */
+#define IG_SLOTS64 768            /* 64-row tiles: 51 KB of LDS, three per CU */
+#define IG_TAIL_FLOATS ((size_t)IG_SLOTS * 128 * 128) /* partial-tile buffer: one slice per slot (768 x 64 x 128 fits too), 33.5 MB */
 size_t mi_igemm_tail_floats(void) { return igemm_mode() ? IG_TAIL_FLOATS : 0; }
 // Workgroup-count quantisation: `tiles` equal workgroups on IG_SLOTS resident slots run in ceil(tiles / IG_SLOTS) rounds, so
 // a last round that fills only a fraction of the chip costs a whole round (ResNet-50 at N=256: the 1024->2048 @14
@@ -685,16 +686,17 @@ size_t mi_igemm_tail_floats(void) { return igemm_mode() ? IG_TAIL_FLOATS : 0; }
 // 104.9 -> 111.3 TFLOP/s).  Measured and rejected: slicing a last round that is more than half full into more than
 // IG_SLOTS slices (several short rounds) -- no gain over leaving it whole (3x3 forward 8.8 vs 8.8 ms/step, projections
 // 12.3 vs 12.1).
-static void igemm_tail_plan(IgArgs &g, int ksteps, float *tailbuf) {
+static void igemm_tail_plan(IgArgs &g, int ksteps, float *tailbuf, int bm) {
+    const int slots = bm == 128 ? IG_SLOTS : IG_SLOTS64;
     g.full = g.tiles; g.tsplit = 1; g.tklen = ksteps; g.tailbuf = tailbuf;
     g.fdTs = make_fastdiv(1);
     static int on = -1;
     if (on < 0) { const char *e = getenv("RESNET_MI_IGEMM_TAIL"); on = e ? atoi(e) : 1; }
     if (!on || !tailbuf) return;
-    const int rem = g.tiles % IG_SLOTS;
+    const int rem = g.tiles % slots;
     if (rem == 0) return;
-    if (rem * 2 > IG_SLOTS) return;                    // the last round is at least half full
-    int s = IG_SLOTS / rem;                            // slices per tail tile: rem * s <= IG_SLOTS
+    if (rem * 2 > slots) return;                       // the last round is at least half full
+    int s = slots / rem;                               // slices per tail tile: rem * s <= slots
     if (s > 16) s = 16;
     while (s > 1 && ksteps / s < 8) s--;               // a slice is at least 8 k-steps
     if (s < 2) return;
@@ -713,15 +715,18 @@ static int igemm_pick_bm(int M, int coltiles, int ksteps) {
     int pick = 128;
     for (int bm = 128; bm >= 64; bm -= 64) {
         const long B = (long)(M / bm) * coltiles;
-        const long rem = B % IG_SLOTS;
+        const long slots = bm == 128 ? IG_SLOTS : IG_SLOTS64;
+        const long rem = B % slots;
         double tail = 0;
         if (rem) {
-            int s = (int)(IG_SLOTS / rem);
+            int s = (int)(slots / rem);
             if (s > 16) s = 16;
             while (s > 1 && ksteps / s < 8) s--;
-            tail = rem * 2 > IG_SLOTS || s < 2 ? 1.0 : 1.0 / s + 0.03;
+            tail = rem * 2 > slots || s < 2 ? 1.0 : 1.0 / s + 0.03;
         }
-        const double t = ((double)(B / IG_SLOTS) + tail) * (bm == 128 ? 1.0 : 0.55);
+        // time of a round: three 64-row workgroups share a CU (3 x 0.5 = 1.5 units of a 128-row workgroup's work, at ~10%
+        // lower efficiency) against two 128-row ones (2 units)
+        const double t = ((double)(B / slots) + tail) * (bm == 128 ? 1.0 : 0.83);
         if (bm == 128 || t < best * 0.97) { if (bm == 128 || t < best) { best = t; pick = bm; } }
     }
     static int force = -1;
@@ -787,7 +792,7 @@ int mi_igemm_fwd(hipStream_t st, mid_workspace *ws, const float *x, const float 
     g.tiles = g.mtiles * mi_cdiv(g.ncols, 128);
     g.fdM = make_fastdiv(g.mtiles);
     g.cpt = C / IG_BK; g.fdCpt = make_fastdiv(g.cpt);
-    igemm_tail_plan(g, T * g.cpt, ws->wt_floats >= (size_t)T * C * K + IG_TAIL_FLOATS ? ws->wt + (size_t)T * C * K : nullptr);
+    igemm_tail_plan(g, T * g.cpt, ws->wt_floats >= (size_t)T * C * K + IG_TAIL_FLOATS ? ws->wt + (size_t)T * C * K : nullptr, bm);
     if (parts) {
         parts->nparts = 0;
         const int np = mi_cdiv(g.ncols, 128) * (bm == 128 ? 2 : 4);
@@ -824,7 +829,7 @@ int mi_igemm_dgrad(hipStream_t st, mid_workspace *ws, const float *w, const floa
     g.fdM = make_fastdiv(g.mtiles);
     g.cpt = K / IG_BK; g.fdCpt = make_fastdiv(g.cpt);
     // (stride 2: the four parity classes of unequal length already fill the rounds; no slicing)
-    igemm_tail_plan(g, T * g.cpt, stride == 1 && ws && ws->wt_floats >= (size_t)T * C * K + IG_TAIL_FLOATS ? ws->wt + (size_t)T * C * K : nullptr);
+    igemm_tail_plan(g, T * g.cpt, stride == 1 && ws && ws->wt_floats >= (size_t)T * C * K + IG_TAIL_FLOATS ? ws->wt + (size_t)T * C * K : nullptr, bm);
     mi_prof_begin(st, igemm_fam(k), 2.0 * T * (double)g.ncols * C * K,
                   4.0 * ((double)g.ncols * K + (double)T * C * K + (double)N * C * g.HW * (addend ? 2 : 1)));
     int rc = igemm_launch<IG_DGRAD>(st, dim3(g.full + (g.tiles - g.full) * g.tsplit, stride == 2 ? 4 : 1), A, dy, dx, addend, g, k, stride, bm);
