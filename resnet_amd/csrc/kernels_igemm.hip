@@ -709,7 +709,7 @@ static void igemm_tail_plan(IgArgs &g, int ksteps, float *tailbuf, int bm) {
 // Rows per workgroup tile.  64-row tiles do ~10% less work per cycle than 128-row ones but halve the granularity: they win
 // where the 128-row grid ends in a mostly empty round that is too full to slice (e.g. 1024->256 @14: 784 tiles = 1.53
 // rounds -> two rounds; 1568 half tiles = 3.06 rounds with a sliced tail).
-static int igemm_pick_bm(int M, int coltiles, int ksteps) {
+static int igemm_pick_bm(int M, int coltiles, int ksteps, int k) {
     if (M % 128) return 64;
     double best = 0;
     int pick = 128;
@@ -726,7 +726,9 @@ static int igemm_pick_bm(int M, int coltiles, int ksteps) {
         }
         // time of a round: three 64-row workgroups share a CU (3 x 0.5 = 1.5 units of a 128-row workgroup's work, at ~10%
         // lower efficiency) against two 128-row ones (2 units)
-        const double t = ((double)(B / slots) + tail) * (bm == 128 ? 1.0 : 0.83);
+        // (fitted on the per-layer sweep: 3x3 layers run fastest with 0.78-0.83, 1x1 with anything <= 0.70 -- their short
+        // reductions favour the finer tiles nearly everywhere)
+        const double t = ((double)(B / slots) + tail) * (bm == 128 ? 1.0 : k == 1 ? 0.70 : 0.80);
         if (bm == 128 || t < best * 0.97) { if (bm == 128 || t < best) { best = t; pick = bm; } }
     }
     static int force = -1;
@@ -787,7 +789,7 @@ int mi_igemm_fwd(hipStream_t st, mid_workspace *ws, const float *x, const float 
     MI_LAUNCH_CHECK("igemm_wt_kernel");
     IgArgs g = {};
     igemm_geometry(g, N, C, H, K, stride);
-    const int bm = igemm_pick_bm(K, mi_cdiv(g.ncols, 128), T * (C / IG_BK));
+    const int bm = igemm_pick_bm(K, mi_cdiv(g.ncols, 128), T * (C / IG_BK), k);
     g.mtiles = K / bm;
     g.tiles = g.mtiles * mi_cdiv(g.ncols, 128);
     g.fdM = make_fastdiv(g.mtiles);
@@ -823,7 +825,7 @@ int mi_igemm_dgrad(hipStream_t st, mid_workspace *ws, const float *w, const floa
     }
     IgArgs g = {};
     igemm_geometry(g, N, C, H, K, stride);
-    const int bm = stride == 1 ? igemm_pick_bm(C, mi_cdiv(g.ncols, 128), T * (K / IG_BK)) : (C % 128 == 0 ? 128 : 64);
+    const int bm = stride == 1 ? igemm_pick_bm(C, mi_cdiv(g.ncols, 128), T * (K / IG_BK), k) : (C % 128 == 0 ? 128 : 64);
     g.mtiles = C / bm;
     g.tiles = g.mtiles * mi_cdiv(g.ncols, 128);
     g.fdM = make_fastdiv(g.mtiles);
