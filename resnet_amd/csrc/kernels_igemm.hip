@@ -652,11 +652,13 @@ int mi_igemm_supported(int op, int N, int C, int H, int K, int k, int stride) {
     if (k == 3 && C == 64 && K % 64 == 0) return 1;      // two taps per column tile (CT64)
     return k == 1 && C % 64 == 0 && K % 128 == 0; // 1x1 with 64 input channels: computed as the transposed product (below)
 }
+#define IG_SLOTS 512              /* 256 CUs x 2 resident workgroups of 128-row tiles (67.6 KB of LDS each) */
+#define IG_SLOTS64 768            /* 64-row tiles: 51 KB of LDS, three per CU */
 static int igemm_wgrad_splits(int N, int C, int H, int K, int k, int stride) {
     const int bm = K % 128 == 0 ? 128 : 64;
     const long tiles = (C == 64 && k == 3 ? 5L : (long)k * k * (C / 128)) * (K / bm);
     const long ksteps = ((long)N * (H / stride) * (H / stride) + IG_BK - 1) / IG_BK;
-    const long slots = 512; // 256 CUs x 2 resident workgroups
+    const long slots = bm == 128 ? IG_SLOTS : IG_SLOTS64; // resident workgroups on the chip
     int best = 1;
     double best_eff = 0;
     for (int s = 1; s <= 512; s++) {
@@ -675,8 +677,6 @@ size_t mi_igemm_part_floats(int N, int C, int H, int K, int k, int stride) {
     return (size_t)igemm_wgrad_splits(N, C, H, K, k, stride) * k * k * K * C;
 }
 
-#define IG_SLOTS 512              /* 256 CUs x 2 resident workgroups of 128-row tiles (67.6 KB of LDS each) */
-#define IG_SLOTS64 768            /* 64-row tiles: 51 KB of LDS, three per CU */
 #define IG_TAIL_FLOATS ((size_t)IG_SLOTS * 128 * 128) /* partial-tile buffer: one slice per slot (768 x 64 x 128 fits too), 33.5 MB */
 size_t mi_igemm_tail_floats(void) { return igemm_mode() ? IG_TAIL_FLOATS : 0; }
 // Workgroup-count quantisation: `tiles` equal workgroups on IG_SLOTS resident slots run in ceil(tiles / IG_SLOTS) rounds, so
