@@ -313,6 +313,10 @@ int mi_op_nhwc_to_nchw(const float *in, float *out, int N, int H, int W, int C);
 /* device-side seeded fill (splitmix64 counter stream, uniform [lo,hi)) -- synthetic operands for micro-benchmarks */
 /* test aid: leaves NaNs in the LDS of every CU (catches kernels that read LDS they did not write) */
 int mi_debug_poison_lds(void);
+/* host-only (no GPU needed): route and grid the launch planners choose for a convolution.  op 0 fwd, 1 dgrad, 2 wgrad.
+ * out[0] 1 = MFMA implicit GEMM / 0 = other kernels, [1] rows per tile, [2] tiles, [3] tiles launched whole, [4] reduction
+ * slices per tail tile, [5] k-steps per slice, [6] wgrad splits, [7] workgroups per class or split, [8] k-steps */
+int mi_debug_conv_plan(int op, int N, int C, int H, int K, int k, int stride, int out[9]);
 int mi_op_fill_uniform(float *out, size_t n, uint64_t seed, float lo, float hi);
 
 #ifdef __cplusplus

@@ -168,6 +168,7 @@ PROTOTYPES = {
     "mi_op_nhwc_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i]),
     "mi_op_fill_uniform": (_i, [_vp, _sz, _u64, _f, _f]),
     "mi_debug_poison_lds": (_i, []),
+    "mi_debug_conv_plan": (_i, [_i] * 7 + [_vp]),
 }
 
 _lib = None

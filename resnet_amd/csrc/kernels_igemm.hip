@@ -902,3 +902,36 @@ extern "C" int mi_debug_igemm_stamps(unsigned long long *dst, int nblocks) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(ig_stamps), sizeof(unsigned long long) * 8 * (size_t)nblocks) == hipSuccess ? 0 : -1;
 }
 #endif
+
+// Host-only view of the launch planners (no GPU touched): which route a convolution takes and with what grid.
+// out[0] route taken (1 implicit GEMM, 0 other kernels), [1] rows per tile, [2] tiles, [3] tiles launched whole, [4] reduction
+// slices per tail tile, [5] k-steps per slice, [6] wgrad splits, [7] workgroups launched (per class / split), [8] k-steps
+extern "C" int mid_igemm_plan(int op, int N, int C, int H, int K, int k, int stride, int out[9]) {
+    for (int i = 0; i < 9; i++) out[i] = 0;
+    if (!mi_igemm_supported(op, N, C, H, K, k, stride)) return 0;
+    out[0] = 1;
+    const int T = k * k;
+    IgArgs g = {};
+    if (op == IGOP_WGRAD) {
+        const bool sw = igemm_wgrad_swapped(C, K, k);
+        const int rows = sw ? C : K, cols = sw ? K : C;
+        igemm_geometry(g, N, cols, H, rows, stride);
+        const int bm = rows % 128 == 0 ? 128 : 64;
+        const int splits = sw ? igemm_wgrad_splits(N, K, H, C, 1, 1) : igemm_wgrad_splits(N, C, H, K, k, stride);
+        const int tiles = sw ? (rows / bm) * (cols / 128) : (C == 64 && k == 3 ? (rows / bm) * ((T + 1) / 2) : (rows / bm) * T * (C / 128));
+        const int kd = N * g.P, klen = mi_cdiv(mi_cdiv(kd, splits), IG_BK) * IG_BK;
+        out[1] = bm; out[2] = tiles; out[3] = tiles; out[4] = 1; out[5] = klen / IG_BK; out[6] = mi_cdiv(kd, klen); out[7] = tiles; out[8] = mi_cdiv(kd, IG_BK);
+        return 1;
+    }
+    igemm_geometry(g, N, C, H, K, stride);
+    const int M = op == IGOP_FWD ? K : C, red = op == IGOP_FWD ? C : K;
+    const int ksteps = T * (red / IG_BK);
+    const int bm = (op == IGOP_FWD || stride == 1) ? igemm_pick_bm(M, mi_cdiv(g.ncols, 128), ksteps, k) : (M % 128 == 0 ? 128 : 64);
+    g.mtiles = M / bm;
+    g.tiles = g.mtiles * mi_cdiv(g.ncols, 128);
+    float dummy;
+    igemm_tail_plan(g, ksteps, (op == IGOP_FWD || stride == 1) ? &dummy : nullptr, bm);
+    out[1] = bm; out[2] = g.tiles; out[3] = g.full; out[4] = g.tsplit; out[5] = g.tklen; out[6] = 1;
+    out[7] = g.full + (g.tiles - g.full) * g.tsplit; out[8] = ksteps;
+    return 1;
+}

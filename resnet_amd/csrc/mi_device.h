@@ -80,6 +80,9 @@ int mid_conv_wgrad(mid_stream s, mid_workspace *ws, const float *x, const float 
 size_t mid_conv_ws_wt_floats(int C, int K, int k);
 size_t mid_conv_ws_part_floats(int N, int C, int H, int K, int k, int stride);
 
+/* host-only: route and grid the launch planners choose for a convolution (kernels_igemm.hip); op 0 fwd, 1 dgrad, 2 wgrad */
+int mid_igemm_plan(int op, int N, int C, int H, int K, int k, int stride, int out[9]);
+
 /* ---- plain GEMMs for the FC layer (row-major) ---- */
 /* out[m x n] = A[m x k] B[k x n] */
 int mid_gemm_nn(mid_stream s, const float *A, const float *B, float *out, int m, int k, int n);

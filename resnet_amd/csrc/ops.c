@@ -95,3 +95,4 @@ int mi_op_adam(float *p, const float *g, float *m, float *v, size_t n, float lr,
 int mi_op_nhwc_to_nchw(const float *in, float *out, int N, int H, int W, int C) { return finish(mid_nhwc_to_nchw(mi_global()->compute, in, out, N, H, W, C)); }
 int mi_op_fill_uniform(float *out, size_t n, uint64_t seed, float lo, float hi) { return finish(mid_fill_uniform(mi_global()->compute, out, n, seed, 0, lo, hi)); }
 int mi_debug_poison_lds(void) { return finish(mid_lds_poison(mi_global()->compute)); }
+int mi_debug_conv_plan(int op, int N, int C, int H, int K, int k, int stride, int out[9]) { return mid_igemm_plan(op, N, C, H, K, k, stride, out); }

@@ -153,3 +153,42 @@ def test_data_parallel_semantics_gloo_world2(tmp_path):
         net.close()
     for i, t in enumerate(total):
         assert np.array_equal(got["arr_%d" % i], t), "location %d" % i
+
+
+def test_conv_launch_planners_on_the_benchmark_shapes():
+    """host-only view of the implicit-GEMM planners (mi_debug_conv_plan; no GPU): for every convolution of the
+    reference-defined ResNet-50 at batch 256 and every operator -- the MFMA route is taken, tiles / slices / splits are
+    consistent, the sliced tail round fits the chip and its partial-tile buffer, and workgroup rounds are well filled."""
+    import ctypes as C
+    from resnet_amd import binding as B
+    L = B.load()
+    layers = [  # (C, H, K, k, stride)
+        (64, 56, 64, 3, 1), (128, 56, 128, 3, 2), (256, 56, 512, 3, 2), (128, 28, 128, 3, 1), (256, 28, 256, 3, 2),
+        (512, 28, 1024, 3, 2), (256, 14, 256, 3, 1), (512, 14, 512, 3, 2), (1024, 14, 2048, 3, 2), (512, 7, 512, 3, 1),
+        (64, 56, 256, 1, 1), (256, 56, 64, 1, 1), (256, 56, 128, 1, 1), (512, 28, 128, 1, 1), (128, 28, 512, 1, 1),
+        (512, 28, 256, 1, 1), (1024, 14, 256, 1, 1), (256, 14, 1024, 1, 1), (1024, 14, 512, 1, 1), (2048, 7, 512, 1, 1),
+        (512, 7, 2048, 1, 1)]
+    N = 256
+    worst = 1.0
+    for (Cc, H, K, k, s) in layers:
+        for op in (0, 1, 2):
+            out = (C.c_int * 9)()
+            assert L.mi_debug_conv_plan(op, N, Cc, H, K, k, s, out) == 1, (op, Cc, H, K, k, s)
+            route, bm, tiles, full, tsplit, tklen, splits, wgs, ksteps = list(out)
+            assert route == 1 and bm in (64, 128) and tiles >= 1 and ksteps >= 1
+            slots = 512 if bm == 128 else 768
+            if op == 2:
+                assert splits >= 1 and tklen * splits >= ksteps > tklen * (splits - 1)  # splits cover the reduction, none empty
+                rounds = tiles * splits / slots
+            else:
+                assert 0 <= full <= tiles and tsplit >= 1 and (tiles - full) * tsplit <= slots        # the sliced round fits the chip
+                assert (tiles - full) * tsplit * bm * 128 <= 512 * 128 * 128                          # and the partial-tile buffer
+                assert tsplit == 1 or (tklen * tsplit >= ksteps > tklen * (tsplit - 1) and tklen >= 8)
+                assert wgs == full + (tiles - full) * tsplit
+                rounds = full / slots + (1.0 / tsplit if tiles > full else 0.0) if tsplit > 1 else tiles / slots
+            fill = rounds / max(1, -(-int(rounds * 1e6) // 10 ** 6)) if tsplit == 1 or op == 2 else 1.0
+            worst = min(worst, fill)
+    assert worst > 0.45, "some layer leaves more than half of its last round of workgroups empty without slicing it"
+    # the stem and a shape that does not tile stay on the other kernels
+    out = (C.c_int * 9)()
+    assert L.mi_debug_conv_plan(0, N, 3, 224, 64, 7, 2, out) == 0 and L.mi_debug_conv_plan(2, N, 48, 8, 80, 3, 1, out) == 0
