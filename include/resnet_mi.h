@@ -264,7 +264,8 @@ int mi_dp_world(const Train_ResNet *t);
 void mi_trainer_last_timings(Train_ResNet *t, float out_ms[5]);
 
 /* optional per-kernel-family timing with HIP events on the launch stream (used by bench.py's roofline):
- * family 0 direct conv fwd/dgrad (3x3, 7x7), 1 direct conv wgrad, 2 MFMA GEMM (1x1 conv, FC), 3 batch norm.
+ * family 0 direct (VALU) conv fwd/dgrad, 1 direct (VALU) conv wgrad, 2 1x1 conv / FC on MFMA, 3 batch norm,
+ * 5 3x3 conv on the MFMA implicit GEMM (fwd, dgrad, wgrad; 4 is unused).
  * flops/bytes are the ALGORITHMIC work of the timed launches. */
 void mi_prof_enable(int on); /* 0 off, 1 all families, otherwise a bit mask of (1 << family) */
 void mi_prof_reset(void);

@@ -57,7 +57,9 @@ typedef struct {
 } mid_workspace;
 
 /* ---- convolution (NCHW activations, KCRS weights), square images/kernels, pad k/2, Ho = H/stride ---- */
-/* 3x3 / 7x7 direct (LDS-tiled, no MFMA); 1x1 goes to the MFMA GEMM.  Returns 0 ok, <0 unsupported shape. */
+/* Routed by shape and RESNET_MI_IGEMM (kernels_igemm.hip: mi_igemm_supported): MFMA implicit GEMM for the 3x3 / 1x1 shapes
+ * that tile, plain MFMA GEMM for other 1x1, direct LDS-tiled VALU kernels for the 7x7 stem and the rest.
+ * Returns 0 ok, <0 unsupported shape. */
 int mid_conv_fwd(mid_stream s, mid_workspace *ws, const float *x, const float *w, float *y, int N, int C, int H, int K,
                  int k, int stride);
 /* Batch-norm statistics fused into the producing convolution: when the layer runs on the implicit-GEMM kernel every
