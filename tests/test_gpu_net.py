@@ -51,13 +51,22 @@ BLOCK_FWD = ["reduction_applied", "reduction_activated", "spatial_applied", "spa
              "output_activated"]
 
 
-@pytest.mark.parametrize("cfg", ["C1", "C1S"])
-def test_training_step_parity(oracle, cfg):
-    dims, batch = (synth.C1_DIMS, synth.C1_BATCH) if cfg == "C1" else (synth.C1S_DIMS, 4)
+@pytest.mark.parametrize("cfg", ["C1", "C1S", "C1S_batch5"])
+def test_training_step_parity(oracle, oracle64, cfg):
+    # batch 5: column counts of every layer are odd multiples (ragged last tiles, images straddling tiles) in a whole step
+    dims, batch = (synth.C1_DIMS, synth.C1_BATCH) if cfg == "C1" else (synth.C1S_DIMS, 5 if cfg.endswith("5") else 4)
     net, tr = _make(dims, batch, oracle)
+    from oracle.oracle_py import OracleNet
+    ref64 = OracleNet(oracle64, dims, batch)  # double-accumulation twin: arbiter for ReLU gates that sit on a rounding error
+    ref64.set_hyper(HYPER["lr"], HYPER["wd"], HYPER["b1"], HYPER["b2"], HYPER["eps"])
+    for i in range(net.n_locations):
+        ref64.param(i)[:] = net.param(i)
     try:
         for step in range(2):
             _step(net, tr, dims, batch, step)
+            im64, lab64 = synth.make_batch(dims, batch, step=step)
+            ref64.set_batch(im64, lab64)
+            ref64.forward()
             # ---- per-layer activations (the second step compounds the first update's ~1e-6 parameter
             # differences through 10 BN layers, hence the wider band there) ----
             rel = ACT_REL_L2 if step == 0 else 5 * ACT_REL_L2
@@ -78,23 +87,39 @@ def test_training_step_parity(oracle, cfg):
             net.backward()
             tr.backward()
             tr.check()
+            ref64.backward()
+            # A pre-activation within rounding of 0 gets its ReLU gate from the summation order: the sequential-fp32 oracle and
+            # its double-accumulation twin then disagree with each other by ~1e-2 on EVERY gradient (C1S, batch 5, second
+            # batch).  For such a step the arbiter is the double-accumulation oracle (closer to exact arithmetic).
+            tol = GRAD_REL_L2 if step == 0 else 3 * GRAD_REL_L2
+            disputed = any(rel_l2(net.grad(i), ref64.grad(i)) > tol for i in range(net.n_locations))
+            ref = ref64 if disputed else net
             for i in range(net.n_locations):
-                check_grad(tr.get("grads", i), net.grad(i), "gradient of location %d step %d" % (i, step),
-                           rel=GRAD_REL_L2 if step == 0 else 3 * GRAD_REL_L2)
+                check_grad(tr.get("grads", i), ref.grad(i), "gradient of location %d step %d%s" % (i, step, " (f64 oracle)" if disputed else ""),
+                           rel=tol)
             # ---- Adam ----
             net.update()
+            ref64.update()
             tr.update()
             tr.check()
             for i in range(net.n_locations):
                 # Adam's first steps are ~lr*sign(g): gradient elements near 0 amplify rounding differences
-                assert rel_l2(tr.get("params", i), net.param(i)) <= PARAM_REL_L2, "param %d" % i
-                check_grad(tr.get("means", i), net.mean(i), "adam mean %d" % i)
-                check_grad(tr.get("vars", i), net.var(i), "adam var %d" % i, rel=2 * GRAD_REL_L2)
+                assert rel_l2(tr.get("params", i), ref.param(i)) <= PARAM_REL_L2, "param %d" % i
+                check_grad(tr.get("means", i), ref.mean(i), "adam mean %d" % i)
+                check_grad(tr.get("vars", i), ref.var(i), "adam var %d" % i, rel=2 * GRAD_REL_L2)
                 assert not np.any(tr.get("grads", i)), "gradients are zeroed after the update (resnet.cu:2972-2978)"
             assert not np.any(tr.activation("input")), "batch buffers are zeroed after the update (resnet.cu:2981)"
+            # The second step starts from ONE state everywhere (the fp32 oracle's): the update itself is pinned above, and
+            # Adam's first update (~lr * sign(g)) turns 1e-7 gradient differences into 1e-5 parameter differences that
+            # flipped ReLU / max-pool decisions can blow up downstream -- a property of comparing fp32 trajectories, not of
+            # a kernel.  Step 1 so tests every kernel with a second batch, nonzero moments and advanced decays.
+            for i in range(net.n_locations):
+                tr.set("params", i, net.param(i)); tr.set("means", i, net.mean(i)); tr.set("vars", i, net.var(i))
+                ref64.param(i)[:] = net.param(i); ref64.mean(i)[:] = net.mean(i); ref64.var(i)[:] = net.var(i)
     finally:
         tr.close()
         net.close()
+        ref64.close()
 
 
 def test_full_store_matches_fast_path(oracle):
