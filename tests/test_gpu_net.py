@@ -46,6 +46,23 @@ def _step(net, tr, dims, batch, step):
     tr.check()
 
 
+def _relu_gate_flips(tr, ref, dims):
+    """ReLU gates on which the HIP forward and a reference forward disagree, and the largest magnitude involved.  A
+    pre-activation within fp32 rounding of 0 (seen: 1.4e-6 where activations are O(1)) takes its gate from the summation
+    order; one flipped gate moves every gradient upstream of it by ~1e-3..1e-2 (BN backward spreads it over the whole
+    channel), so gradients can only be compared tightly against a reference with the SAME gates."""
+    names = ["init_conv_activated"] + ["conv_blocks/%02d/%s" % (b, l) for b in range(dims["n_conv_blocks"])
+                                       for l in ("reduction_activated", "spatial_activated", "output_activated")]
+    flips, mag = 0, 0.0
+    for nm in names:
+        g, r = nhwc(tr.activation(nm)), ref.tensor(nm)
+        d = (g > 0) != (r > 0)
+        if d.any():
+            flips += int(d.sum())
+            mag = max(mag, float(np.abs(g[d]).max()), float(np.abs(r[d]).max()))
+    return flips, mag
+
+
 FWD_NAMES = ["init_conv_applied", "init_conv_activated", "init_convblock_input"]
 BLOCK_FWD = ["reduction_applied", "reduction_activated", "spatial_applied", "spatial_activated", "expanded_applied",
              "output_activated"]
@@ -94,19 +111,23 @@ def test_training_step_parity(oracle, oracle64, cfg):
             tol = GRAD_REL_L2 if step == 0 else 3 * GRAD_REL_L2
             disputed = any(rel_l2(net.grad(i), ref64.grad(i)) > tol for i in range(net.n_locations))
             ref = ref64 if disputed else net
+            flips, mag = _relu_gate_flips(tr, ref, dims)
+            if flips:  # the HIP forward shares neither oracle's gates on a rounding-level element (see _relu_gate_flips)
+                assert flips <= 4 and mag <= 1e-5, "ReLU gates differ on %d elements up to magnitude %.2e" % (flips, mag)
             for i in range(net.n_locations):
                 check_grad(tr.get("grads", i), ref.grad(i), "gradient of location %d step %d%s" % (i, step, " (f64 oracle)" if disputed else ""),
-                           rel=tol)
+                           rel=tol if flips == 0 else 3e-2)
             # ---- Adam ----
             net.update()
             ref64.update()
             tr.update()
             tr.check()
             for i in range(net.n_locations):
-                # Adam's first steps are ~lr*sign(g): gradient elements near 0 amplify rounding differences
-                assert rel_l2(tr.get("params", i), ref.param(i)) <= PARAM_REL_L2, "param %d" % i
-                check_grad(tr.get("means", i), ref.mean(i), "adam mean %d" % i)
-                check_grad(tr.get("vars", i), ref.var(i), "adam var %d" % i, rel=2 * GRAD_REL_L2)
+                if flips == 0:  # (with a flipped gate the gradients fed to Adam differ: the update is pinned by the other steps)
+                    # Adam's first steps are ~lr*sign(g): gradient elements near 0 amplify rounding differences
+                    assert rel_l2(tr.get("params", i), ref.param(i)) <= PARAM_REL_L2, "param %d" % i
+                    check_grad(tr.get("means", i), ref.mean(i), "adam mean %d" % i)
+                    check_grad(tr.get("vars", i), ref.var(i), "adam var %d" % i, rel=2 * GRAD_REL_L2)
                 assert not np.any(tr.get("grads", i)), "gradients are zeroed after the update (resnet.cu:2972-2978)"
             assert not np.any(tr.activation("input")), "batch buffers are zeroed after the update (resnet.cu:2981)"
             # The second step starts from ONE state everywhere (the fp32 oracle's): the update itself is pinned above, and
@@ -298,3 +319,49 @@ def test_reference_resnet50_step_parity(oracle, oracle64):
         tr.close()
         net.close()
         ref.close()
+
+
+OTHER_DIMS = {
+    # reductions in other places, a striding FIRST block (3x3-s2 projection from the 64-channel pool output), two striding
+    # blocks in a row, 64x64 input: shapes the benchmark network does not contain
+    "stride_first": (synth.resnet_dims(input=32, n_conv_blocks=2, reductions=(0,), final_depth=512), 3),
+    "two_strides": (synth.resnet_dims(input=64, n_conv_blocks=4, reductions=(1, 2), final_depth=1024), 2),
+    "six_blocks": (synth.resnet_dims(input=32, n_conv_blocks=6, reductions=(2, 4), final_depth=1024), 3),
+}
+
+
+@pytest.mark.parametrize("name", sorted(OTHER_DIMS))
+def test_other_reference_defined_nets(oracle, oracle64, name):
+    """`Dims` can express any bottleneck net (init_dimensions, resnet.cu:666): three more of them, one forward + backward
+    against the oracle -- loss, last activation, every gradient (the f64 oracle arbitrates a step whose fp32 oracle sits on
+    a flipped ReLU gate, as in test_training_step_parity)."""
+    from oracle.oracle_py import OracleNet
+    dims, batch = OTHER_DIMS[name]
+    net, tr = _make(dims, batch, oracle)
+    ref64 = OracleNet(oracle64, dims, batch)
+    try:
+        for i in range(net.n_locations):
+            ref64.param(i)[:] = net.param(i)
+        im, lab = synth.make_batch(dims, batch, step=0)
+        ref64.set_batch(im, lab)
+        _step(net, tr, dims, batch, 0)
+        ref64.forward()
+        last = "conv_blocks/%02d/output_activated" % (dims["n_conv_blocks"] - 1)
+        check_act(nhwc(tr.activation(last)), net.tensor(last), last)
+        (gl, gw), (ol, ow) = tr.loss(), net.loss()
+        assert abs(gl - ol) <= LOSS_ABS * max(1.0, abs(ol)) and gw == ow
+        net.backward(); tr.backward(); tr.check(); ref64.backward()
+        # compare against the oracle whose ReLU gates the HIP forward shares; if it shares neither's (a gate sitting on a
+        # rounding error: its magnitude must be at rounding level), the gradients can only agree loosely
+        f32_flips, f32_mag = _relu_gate_flips(tr, net, dims)
+        f64_flips, f64_mag = _relu_gate_flips(tr, ref64, dims)
+        ref, flips, mag = (net, f32_flips, f32_mag) if f32_flips <= f64_flips else (ref64, f64_flips, f64_mag)
+        if flips:
+            assert flips <= 4 and mag <= 1e-5, "ReLU gates differ on %d elements up to magnitude %.2e" % (flips, mag)
+        for i in range(net.n_locations):
+            check_grad(tr.get("grads", i), ref.grad(i), "%s: gradient of location %d (%d flipped gates)" % (name, i, flips),
+                       rel=GRAD_REL_L2 if flips == 0 else 3e-2)
+    finally:
+        tr.close()
+        net.close()
+        ref64.close()
