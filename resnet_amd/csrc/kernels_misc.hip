@@ -69,6 +69,39 @@ maxpool_bwd_kernel(const int *__restrict__ idx, const float *__restrict__ dy, fl
     }
 }
 
+// The reference's pooling (3x3 window, stride 2, pad 1, even H): one thread per 2x2 input cell (2a..2a+1, 2b..2b+1).  Only
+// the windows (a..a+1, b..b+1) reach the cell -- four (index, dy) pairs serve four outputs (the general kernel above looks up
+// 2.25 windows per element) and the result leaves as two 8-byte stores.  Same "last writer in (oh, ow) scan order" rule.
+__global__ void __launch_bounds__(256)
+maxpool_bwd_3x3s2_kernel(const int *__restrict__ idx, const float *__restrict__ dy, float *__restrict__ dx, uint32_t cells, int H,
+                         int Ho, FastDiv fdHo) {
+    for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < cells; q += gridDim.x * 256u) {
+        const uint32_t t = fd_div(q, fdHo);
+        const int b = (int)(q - t * Ho);
+        const uint32_t nc = fd_div(t, fdHo);
+        const int a = (int)(t - nc * Ho);
+        const uint32_t obase = nc * (uint32_t)(Ho * Ho), ibase = nc * (uint32_t)(H * H);
+        const bool a1 = a + 1 < Ho, b1 = b + 1 < Ho;
+        const uint32_t o00 = obase + a * Ho + b;
+        const int i00 = idx[o00], i01 = b1 ? idx[o00 + 1] : -1, i10 = a1 ? idx[o00 + Ho] : -1, i11 = (a1 && b1) ? idx[o00 + Ho + 1] : -1;
+        const float d00 = dy[o00], d01 = b1 ? dy[o00 + 1] : 0.f, d10 = a1 ? dy[o00 + Ho] : 0.f, d11 = (a1 && b1) ? dy[o00 + Ho + 1] : 0.f;
+        const int e00 = (int)ibase + (2 * a) * H + 2 * b, e01 = e00 + 1, e10 = e00 + H, e11 = e10 + 1;
+        float v00 = 0.f, v01 = 0.f, v10 = 0.f, v11 = 0.f;
+        // windows in scan order (a,b), (a,b+1), (a+1,b), (a+1,b+1): a later match overwrites an earlier one
+        if (i00 == e00) v00 = d00;
+        if (i00 == e01) v01 = d00;
+        if (i01 == e01) v01 = d01;
+        if (i00 == e10) v10 = d00;
+        if (i10 == e10) v10 = d10;
+        if (i00 == e11) v11 = d00;
+        if (i01 == e11) v11 = d01;
+        if (i10 == e11) v11 = d10;
+        if (i11 == e11) v11 = d11;
+        *(float2 *)(dx + e00) = make_float2(v00, v01);
+        *(float2 *)(dx + e10) = make_float2(v10, v11);
+    }
+}
+
 // ---- global average pool: one wave per (n,c) plane ----
 __global__ void __launch_bounds__(256) avgpool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int NC, int P) {
     const int lane = threadIdx.x & 63;
@@ -215,6 +248,13 @@ int mid_maxpool_bwd(mid_stream s, const int *max_inds, const float *dy, float *d
     const int Ho = H / stride;
     const size_t total = (size_t)N * C * H * H;
     if ((double)total >= 2147483648.0) { mi_record_error("mid_maxpool_bwd", "tensor too large for 32-bit indices"); return -2; }
+    if (k == 3 && stride == 2 && (H & 1) == 0) {
+        const size_t cells = total / 4;
+        hipLaunchKernelGGL(maxpool_bwd_3x3s2_kernel, dim3(ew_blocks(cells)), dim3(256), 0, (hipStream_t)s, max_inds, dy, dx, (uint32_t)cells, H, Ho,
+                           make_fastdiv(Ho));
+        MI_LAUNCH_CHECK("maxpool_bwd_3x3s2_kernel");
+        return 0;
+    }
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)s, max_inds, dy, dx, (uint32_t)total, H, Ho, k,
                        stride, make_fastdiv(H));
     MI_LAUNCH_CHECK("maxpool_bwd_kernel");
