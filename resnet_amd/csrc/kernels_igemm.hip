@@ -604,7 +604,20 @@ igemm_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw
     float s[T];
 #pragma unroll
     for (int t = 0; t < T; t++) s[t] = 0.f;
-    for (int z = 0; z < splits; z++)
+    constexpr int U = T == 1 ? 8 : 2; // partials of U splits in flight per thread (one split per trip was latency-bound)
+    int z = 0;
+    for (; z + U <= splits; z += U) {
+        float v[U][T];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int t = 0; t < T; t++) v[u][t] = part[((long)(z + u) * T + t) * KC + i];
+#pragma unroll
+        for (int u = 0; u < U; u++) // ascending split order, as before
+#pragma unroll
+            for (int t = 0; t < T; t++) s[t] += v[u][t];
+    }
+    for (; z < splits; z++)
 #pragma unroll
         for (int t = 0; t < T; t++) s[t] += part[((long)z * T + t) * KC + i];
 #pragma unroll
@@ -617,7 +630,15 @@ igemm_wgrad_reduce_t_kernel(const float *__restrict__ part, float *__restrict__ 
     const long i = (long)blockIdx.x * 256 + threadIdx.x; // over [c][k]: coalesced reads
     if (i >= (long)K * C) return;
     float s = 0.f;
-    for (int z = 0; z < splits; z++) s += part[(long)z * K * C + i];
+    int z = 0;
+    for (; z + 8 <= splits; z += 8) { // eight partials in flight, summed in ascending split order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = part[(long)(z + u) * K * C + i];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += v[u];
+    }
+    for (; z < splits; z++) s += part[(long)z * K * C + i];
     const int c = (int)(i / K), kk = (int)(i - (long)c * K);
     dw[(long)kk * C + c] = s;
 }
