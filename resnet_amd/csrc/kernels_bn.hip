@@ -155,16 +155,18 @@ bn_parts_merge_kernel(const float *__restrict__ parts, int np, int C, float *__r
     }
 }
 
-// per-channel finalize: merges the split partials in fixed order; writes mean / biased var
-__global__ void bn_finalize_kernel(const float *__restrict__ partial, int nsplit, int C, float *__restrict__ means,
-                                   float *__restrict__ vars) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// per-channel finalize: one wave per channel, lane i holds split partial i (nsplit <= 64), butterfly Chan merge (a fixed
+// tree: deterministic); writes mean / biased var.  (One thread per channel merging 64 partials in sequence took 10 us per
+// launch on the critical path of every BN.)
+__global__ void __launch_bounds__(256)
+bn_finalize_kernel(const float *__restrict__ partial, int nsplit, int C, float *__restrict__ means, float *__restrict__ vars) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     const float *p = partial + (size_t)c * BN_SPLIT_MAX * 3;
-    Wel r = {p[0], p[1], p[2]};
-    for (int i = 1; i < nsplit; i++) { Wel b = {p[i * 3], p[i * 3 + 1], p[i * 3 + 2]}; r = wel_merge(r, b); }
-    means[c] = r.mean;
-    vars[c] = r.m2 / r.n;
+    Wel w = {0.f, 0.f, 0.f};
+    if (lane < nsplit) { w.n = p[lane * 3]; w.mean = p[lane * 3 + 1]; w.m2 = p[lane * 3 + 2]; }
+    w = wel_wave(w);
+    if (lane == 0) { means[c] = w.mean; vars[c] = w.m2 / w.n; }
 }
 
 // x_hat and y exactly as the reference writes them (resnet.cu:329-331); shared by forward and the backward
@@ -305,15 +307,15 @@ bn_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ dy, 
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(float *__restrict__ partial, int nsplit, int C, float *__restrict__ dgamma,
-                                       float *__restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256)
+bn_bwd_finalize_kernel(float *__restrict__ partial, int nsplit, int C, float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63; // one wave per channel, lane = split
     if (c >= C) return;
-    float *p = partial + (size_t)c * BN_SPLIT_MAX * 3;
+    const float *p = partial + (size_t)c * BN_SPLIT_MAX * 3;
     float s1 = 0.f, s2 = 0.f;
-    for (int i = 0; i < nsplit; i++) { s1 += p[i * 3]; s2 += p[i * 3 + 1]; }
-    dbeta[c] = s1;
-    dgamma[c] = s2;
+    if (lane < nsplit) { s1 = p[lane * 3]; s2 = p[lane * 3 + 1]; }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) { dbeta[c] = s1; dgamma[c] = s2; }
 }
 
 template <int MASK, bool VEC>
@@ -396,7 +398,7 @@ int mid_bn_fwd(mid_stream s, float *ws, const float *x, const float *gamma, cons
     if ((P & 3) == 0) hipLaunchKernelGGL((bn_stats_kernel<true>), dim3(C, ns), dim3(256), 0, st, x, ws, N, C, P, make_fastdiv(P / 4));
     else hipLaunchKernelGGL((bn_stats_kernel<false>), dim3(C, ns), dim3(256), 0, st, x, ws, N, C, P, make_fastdiv(P));
     MI_LAUNCH_CHECK("bn_stats_kernel");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(mi_cdiv(C, 64)), dim3(64), 0, st, ws, ns, C, means, vars);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(mi_cdiv(C, 4)), dim3(256), 0, st, ws, ns, C, means, vars);
     MI_LAUNCH_CHECK("bn_finalize_kernel");
     const int rc = bn_fwd_apply(st, x, gamma, beta, residual, means, vars, y, xhat_out, norm_out, N, C, P, eps, relu);
     mi_prof_end(st);
@@ -416,7 +418,7 @@ int mid_bn_fwd_parts(mid_stream s, float *ws, const mid_bn_parts *parts, const f
     mi_prof_begin(st, MI_FAM_BN, 0.0, 4.0 * (double)N * C * P * (residual ? 3 : 2));
     hipLaunchKernelGGL(bn_parts_merge_kernel, dim3(mi_cdiv(C, 64), G), dim3(256), 0, st, parts->buf, parts->nparts, C, ws);
     MI_LAUNCH_CHECK("bn_parts_merge_kernel");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(mi_cdiv(C, 64)), dim3(64), 0, st, ws, G, C, means, vars);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(mi_cdiv(C, 4)), dim3(256), 0, st, ws, G, C, means, vars);
     MI_LAUNCH_CHECK("bn_finalize_kernel");
     const int rc = bn_fwd_apply(st, x, gamma, beta, residual, means, vars, y, xhat_out, norm_out, N, C, P, eps, relu);
     mi_prof_end(st);
@@ -441,7 +443,7 @@ static int bn_bwd_impl(hipStream_t st, float *ws, const float *x, const float *g
     else { if (rvec) BWD_REDUCE(3, true); else BWD_REDUCE(3, false); }
 #undef BWD_REDUCE
     MI_LAUNCH_CHECK("bn_bwd_reduce_kernel");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(mi_cdiv(C, 64)), dim3(64), 0, st, ws, ns, C, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(mi_cdiv(C, 4)), dim3(256), 0, st, ws, ns, C, dgamma, dbeta);
     MI_LAUNCH_CHECK("bn_bwd_finalize_kernel");
     const size_t total = (size_t)N * C * P;
     const FastDiv fdP = make_fastdiv(P), fdC = make_fastdiv(C);
