@@ -595,6 +595,26 @@ igemm_wt_kernel(const float *__restrict__ w, float *__restrict__ out, int K, int
     }
 }
 
+// The same re-layout for MANY layers in one launch (mid_conv_prelayout_all: the trainer runs it once at the start of a
+// forward pass instead of 71 small launches in front of the convolutions): block = one 32 x 32 (k, c) tile of one layer.
+__global__ void __launch_bounds__(256)
+igemm_wt_all_kernel(const mid_wt_entry *__restrict__ entries, const int *__restrict__ tile_entry) {
+    __shared__ float tile[32][9 * 32 + 1];
+    const mid_wt_entry E = entries[tile_entry[blockIdx.x]];
+    const int tl = (int)blockIdx.x - E.tile0, ctiles = E.C / 32, T = E.T;
+    const int c0 = (tl % ctiles) * 32, k0 = (tl / ctiles) * 32, row = T * 32;
+    for (int e = threadIdx.x; e < 32 * row; e += 256) {
+        const int kr = e / row, x = e - kr * row;
+        tile[kr][x] = E.w[((size_t)(k0 + kr) * E.C + c0) * T + x];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < T * 1024; e += 256) {
+        const int t = e >> 10, u = (e >> 5) & 31, v = e & 31; // v fastest = contiguous output dim
+        if (E.fwd) E.fwd[((size_t)t * E.C + c0 + u) * E.K + k0 + v] = tile[v][u * T + t];
+        if (E.dgrad) E.dgrad[((size_t)t * E.K + k0 + u) * E.C + c0 + v] = tile[u][v * T + t];
+    }
+}
+
 // dW[k][c][t] = sum_z part[z][t][k][c] in ascending z (deterministic)
 template <int T>
 __global__ void __launch_bounds__(256)
@@ -805,9 +825,13 @@ int mi_igemm_fwd(hipStream_t st, mid_workspace *ws, const float *x, const float 
                  int stride, mid_bn_parts *parts) {
     const int T = k * k;
     if (!ws || ws->wt_floats < (size_t)T * C * K) { mi_record_error("mi_igemm_fwd", "workspace too small"); return -3; }
-    if (k == 1) hipLaunchKernelGGL(igemm_wt_kernel<1>, dim3(C / 32, K / 32), dim3(256), 0, st, w, ws->wt, K, C, 1);
-    else hipLaunchKernelGGL(igemm_wt_kernel<9>, dim3(C / 32, K / 32), dim3(256), 0, st, w, ws->wt, K, C, 1);
-    MI_LAUNCH_CHECK("igemm_wt_kernel");
+    const float *A = ws->pre_fwd; // re-laid [t][c][k] by mid_conv_prelayout_all, else done here
+    if (!A) {
+        if (k == 1) hipLaunchKernelGGL(igemm_wt_kernel<1>, dim3(C / 32, K / 32), dim3(256), 0, st, w, ws->wt, K, C, 1);
+        else hipLaunchKernelGGL(igemm_wt_kernel<9>, dim3(C / 32, K / 32), dim3(256), 0, st, w, ws->wt, K, C, 1);
+        MI_LAUNCH_CHECK("igemm_wt_kernel");
+        A = ws->wt;
+    }
     IgArgs g = {};
     igemm_geometry(g, N, C, H, K, stride);
     const int bm = igemm_pick_bm(K, mi_cdiv(g.ncols, 128), T * (C / IG_BK), k);
@@ -823,7 +847,7 @@ int mi_igemm_fwd(hipStream_t st, mid_workspace *ws, const float *x, const float 
     }
     mi_prof_begin(st, igemm_fam(k), 2.0 * T * (double)g.ncols * C * K,
                   4.0 * ((double)N * C * g.HW + (double)T * C * K + (double)g.ncols * K));
-    int rc = igemm_launch<IG_FWD>(st, dim3(g.full + (g.tiles - g.full) * g.tsplit), ws->wt, x, y, nullptr, g, k, stride, bm);
+    int rc = igemm_launch<IG_FWD>(st, dim3(g.full + (g.tiles - g.full) * g.tsplit), A, x, y, nullptr, g, k, stride, bm);
     if (!rc && g.tsplit > 1) {
         if (bm == 128) hipLaunchKernelGGL((igemm_tail_reduce_kernel<IG_FWD, 128>), dim3(g.tiles - g.full, 8), dim3(256), 0, st, y, nullptr, g);
         else hipLaunchKernelGGL((igemm_tail_reduce_kernel<IG_FWD, 64>), dim3(g.tiles - g.full, 4), dim3(256), 0, st, y, nullptr, g);
@@ -840,9 +864,12 @@ int mi_igemm_dgrad(hipStream_t st, mid_workspace *ws, const float *w, const floa
     const float *A = w; // 1x1: the KC tensor is already [k][c]
     if (k == 3) {
         if (!ws || ws->wt_floats < (size_t)T * C * K) { mi_record_error("mi_igemm_dgrad", "workspace too small"); return -3; }
-        hipLaunchKernelGGL(igemm_wt_kernel<9>, dim3(C / 32, K / 32), dim3(256), 0, st, w, ws->wt, K, C, 0);
-        MI_LAUNCH_CHECK("igemm_wt_kernel");
-        A = ws->wt;
+        if (ws->pre_dgrad) A = ws->pre_dgrad;
+        else {
+            hipLaunchKernelGGL(igemm_wt_kernel<9>, dim3(C / 32, K / 32), dim3(256), 0, st, w, ws->wt, K, C, 0);
+            MI_LAUNCH_CHECK("igemm_wt_kernel");
+            A = ws->wt;
+        }
     }
     IgArgs g = {};
     igemm_geometry(g, N, C, H, K, stride);
@@ -955,4 +982,15 @@ extern "C" int mid_igemm_plan(int op, int N, int C, int H, int K, int k, int str
     out[1] = bm; out[2] = g.tiles; out[3] = g.full; out[4] = g.tsplit; out[5] = g.tklen; out[6] = 1;
     out[7] = g.full + (g.tiles - g.full) * g.tsplit; out[8] = ksteps;
     return 1;
+}
+
+extern "C" int mid_conv_prelayout_all(mid_stream s, const mid_wt_entry *entries_dev, const int *tile_entry_dev, int ntiles) {
+    if (ntiles <= 0) return 0;
+    hipLaunchKernelGGL(igemm_wt_all_kernel, dim3(ntiles), dim3(256), 0, (hipStream_t)s, entries_dev, tile_entry_dev);
+    MI_LAUNCH_CHECK("igemm_wt_all_kernel");
+    return 0;
+}
+extern "C" void mid_conv_prelayout_needs(int N, int C, int H, int K, int k, int stride, int *need_fwd, int *need_dgrad) {
+    *need_fwd = mi_igemm_supported(IGOP_FWD, N, C, H, K, k, stride) ? 1 : 0;
+    *need_dgrad = (k == 3 && mi_igemm_supported(IGOP_DGRAD, N, C, H, K, k, stride)) ? 1 : 0; // 1x1 dgrad reads the KC tensor itself
 }

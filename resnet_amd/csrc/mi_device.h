@@ -54,7 +54,21 @@ typedef struct {
     size_t wt_floats;
     float *part;      /* split-reduction partial sums */
     size_t part_floats;
+    /* weights of the NEXT call already re-laid by mid_conv_prelayout_all (else NULL: the call re-lays them itself into wt) */
+    const float *pre_fwd, *pre_dgrad;
 } mid_workspace;
+
+/* One launch that re-lays the weights of many convolutions for the implicit-GEMM kernel: fwd = [t][c][k], dgrad = [t][k][c]
+ * (either may be NULL).  entries / tile_entry live in device memory; tile0 = first 32x32 (k, c) tile of the entry in the
+ * launch's flat tile numbering, tile_entry[tile] = its entry. */
+typedef struct {
+    const float *w;
+    float *fwd, *dgrad;
+    int K, C, T, tile0;
+} mid_wt_entry;
+int mid_conv_prelayout_all(mid_stream s, const mid_wt_entry *entries_dev, const int *tile_entry_dev, int ntiles);
+/* which pre-laid forms the implicit-GEMM route of this layer would use (0/1 each); both 0 = layer not on that route */
+void mid_conv_prelayout_needs(int N, int C, int H, int K, int k, int stride, int *need_fwd, int *need_dgrad);
 
 /* ---- convolution (NCHW activations, KCRS weights), square images/kernels, pad k/2, Ho = H/stride ---- */
 /* Routed by shape and RESNET_MI_IGEMM (kernels_igemm.hip: mi_igemm_supported): MFMA implicit GEMM for the 3x3 / 1x1 shapes

@@ -46,6 +46,12 @@ typedef struct MiCtx {
     mid_workspace ws;
     float *bn_ws;
     mid_bn_parts bn_parts; /* statistics partials a forward convolution leaves for its batch norm */
+    /* weights re-laid for the implicit-GEMM kernel once per forward pass (one launch): host copy of the table for the
+     * per-call lookup by weight pointer, device copies for the kernel */
+    mid_wt_entry *wt_tab;
+    int wt_n, wt_tiles;
+    mid_wt_entry *wt_tab_dev;
+    int *wt_tile_entry_dev;
     int fuse_bn_stats;
     int *nan_flag_dev, *nan_flag_host;
     int full_store, dump_every, input_reset;

@@ -316,6 +316,47 @@ static void size_workspaces(MiCtx *c, const Dims *d, ConvBlock **blocks, int N) 
         c->bn_parts.nparts = 0;
         c->fuse_bn_stats = getenv("RESNET_MI_BNFUSE") ? atoi(getenv("RESNET_MI_BNFUSE")) : 1;
     }
+    { /* table of the convolutions whose weights are re-laid once per forward pass (mid_conv_prelayout_all) */
+        const int maxn = 4 * d->n_conv_blocks + 1;
+        const int prelayout = getenv("RESNET_MI_PRELAYOUT") ? atoi(getenv("RESNET_MI_PRELAYOUT")) : 1; /* 0: each conv re-lays its own */
+        c->wt_tab = (mid_wt_entry *)calloc((size_t)maxn, sizeof(mid_wt_entry));
+        c->wt_n = 0; c->wt_tiles = 0;
+#define WT_LAYER(w_, C_, H_, K_, k_, s_)                                                       \
+        do {                                                                                       \
+            int nf_ = 0, nd_ = 0;                                                                  \
+            if ((w_) && prelayout) mid_conv_prelayout_needs(N, C_, H_, K_, k_, s_, &nf_, &nd_); \
+            if (nf_ || nd_) {                                                                      \
+                mid_wt_entry *e_ = &c->wt_tab[c->wt_n++];                                          \
+                const size_t n_ = (size_t)(k_) * (k_) * (C_) * (K_);                               \
+                e_->w = (w_); e_->K = (K_); e_->C = (C_); e_->T = (k_) * (k_);                     \
+                e_->fwd = nf_ ? falloc(c, n_) : NULL; e_->dgrad = nd_ ? falloc(c, n_) : NULL;      \
+                e_->tile0 = c->wt_tiles; c->wt_tiles += ((C_) / 32) * ((K_) / 32);                 \
+            }                                                                                      \
+        } while (0)
+        for (int i = 0; i < d->n_conv_blocks; i++) {
+            const ConvBlock *b = blocks[i];
+            const int H = b->incoming_spatial_dim;
+            WT_LAYER(b->depth_reduction, b->incoming_filters, H, b->reduced_depth, 1, 1);
+            WT_LAYER(b->spatial, b->reduced_depth, H, b->reduced_depth, 3, b->stride);
+            WT_LAYER(b->depth_expansion, b->reduced_depth, H / b->stride, b->expanded_depth, 1, 1);
+            WT_LAYER(b->projection, b->incoming_filters, H, b->expanded_depth, b->stride == 2 ? 3 : 1, b->stride);
+        }
+#undef WT_LAYER
+        c->wt_tab_dev = NULL; c->wt_tile_entry_dev = NULL;
+        if (c->wt_n) {
+            int *te = (int *)malloc((size_t)c->wt_tiles * sizeof(int));
+            for (int e = 0; e < c->wt_n; e++) {
+                const int nt = (c->wt_tab[e].C / 32) * (c->wt_tab[e].K / 32);
+                for (int q = 0; q < nt; q++) te[c->wt_tab[e].tile0 + q] = e;
+            }
+            c->wt_tab_dev = (mid_wt_entry *)mi_ctx_alloc(c, (size_t)c->wt_n * sizeof(mid_wt_entry));
+            c->wt_tile_entry_dev = (int *)mi_ctx_alloc(c, (size_t)c->wt_tiles * sizeof(int));
+            mid_memcpy_h2d(c->wt_tab_dev, c->wt_tab, (size_t)c->wt_n * sizeof(mid_wt_entry), G.compute);
+            mid_memcpy_h2d(c->wt_tile_entry_dev, te, (size_t)c->wt_tiles * sizeof(int), G.compute);
+            mid_stream_sync(G.compute);
+            free(te);
+        }
+    }
 }
 
 /* resnet.cu:1157-1194 */
@@ -436,6 +477,12 @@ void mi_trainer_last_timings(Train_ResNet *t, float out_ms[5]) {
 }
 
 /* ---------------------------------------------------------------------------------------------- */
+static const mid_wt_entry *wt_lookup(const MiCtx *c, const float *w) {
+    for (int i = 0; i < c->wt_n; i++)
+        if (c->wt_tab[i].w == w) return &c->wt_tab[i];
+    return NULL;
+}
+
 /* conv + BN (+ReLU | +residual+ReLU): prepareAndDoConvolution + prepareAndDoBatchNormAndActivate     */
 static void unit_fwd(Train_ResNet *t, const float *in, const float *w, const BatchNorm *bn, Cache_BatchNorm *cache,
                      float *conv_out, float *act_out, const float *residual, int C, int H, int K, int k, int stride,
@@ -443,7 +490,10 @@ static void unit_fwd(Train_ResNet *t, const float *in, const float *w, const Bat
     MiCtx *c = ctx_of(t);
     const int N = t->batch_size, Ho = H / stride;
     /* the convolution leaves per-tile (count, mean, M2) partials of its output: BN reads the tensor twice, not three times */
+    const mid_wt_entry *we = wt_lookup(c, w);
+    c->ws.pre_fwd = we ? we->fwd : NULL; /* re-laid at the start of this forward pass */
     mid_conv_fwd_stats(G.compute, &c->ws, in, w, conv_out, N, C, H, K, k, stride, c->fuse_bn_stats ? &c->bn_parts : NULL);
+    c->ws.pre_fwd = NULL;
     mid_bn_fwd_parts(G.compute, c->bn_ws, c->fuse_bn_stats ? &c->bn_parts : NULL, conv_out, bn->gamma, bn->beta, residual,
                      cache->means, cache->vars, act_out, cache->normalized_temp, cache->normalized, N, K, Ho * Ho, t->eps, relu);
 }
@@ -456,6 +506,9 @@ void forward_pass(Train_ResNet *t) {
     Activations *a = t->forward_buffer->activations;
     const int N = t->batch_size, f = d->init_conv_filters;
     mid_event_record(c->ev_t[0], G.compute);
+    /* every implicit-GEMM layer's weights in the layouts forward and dgrad want, one launch (they hold until the next
+     * update_parameters; a caller that rewrites parameters between forward_pass and backwards_pass is not supported) */
+    mid_conv_prelayout_all(G.compute, c->wt_tab_dev, c->wt_tile_entry_dev, c->wt_tiles);
     unit_fwd(t, t->cur_batch->images, p->init_conv_layer, p->norm_init_conv, a->norm_init_conv, a->init_conv_applied,
              a->init_conv_activated, NULL, 3, d->input, f, d->init_kernel_dim, d->init_conv_stride, 1);
     const int Hs = d->input / d->init_conv_stride;
@@ -552,11 +605,11 @@ static void unit_bwd(Train_ResNet *t, const float *in, const float *w, const Bat
         c->ring_busy[d_slot] = 1;
         mid_event_record(c->ev_wgrad_done, G.aux);
         c->wgrad_pending = 1;
-        if (dx) mid_conv_dgrad(G.compute, &c->ws, w, d_conv_out, dx, addend, N, C, H, K, k, stride);
+        if (dx) { const mid_wt_entry *we = wt_lookup(c, w); c->ws.pre_dgrad = we ? we->dgrad : NULL; mid_conv_dgrad(G.compute, &c->ws, w, d_conv_out, dx, addend, N, C, H, K, k, stride); c->ws.pre_dgrad = NULL; }
         return;
     }
     join_wgrad(c);
-    if (dx) mid_conv_dgrad(G.compute, &c->ws, w, d_conv_out, dx, addend, N, C, H, K, k, stride);
+    if (dx) { const mid_wt_entry *we = wt_lookup(c, w); c->ws.pre_dgrad = we ? we->dgrad : NULL; mid_conv_dgrad(G.compute, &c->ws, w, d_conv_out, dx, addend, N, C, H, K, k, stride); c->ws.pre_dgrad = NULL; }
     if (c->overlap_wgrad) {
         mid_event_record(c->ev_bn_done, G.compute);
         mid_stream_wait_event(G.aux, c->ev_bn_done);
@@ -723,6 +776,7 @@ void destroy_trainer(Train_ResNet *t) {
     mid_free_host(t->forward_buffer->pred_cpu);
     mid_free_host(c->nan_flag_host);
     mid_event_destroy(c->ev_grads); mid_event_destroy(c->ev_reduced);
+    free(c->wt_tab);
     mid_event_destroy(c->ev_bn_done); mid_event_destroy(c->ev_wgrad_done);
     for (int i = 0; i < MI_RING; i++) mid_event_destroy(c->ring_ev[i]);
     for (int i = 0; i < 6; i++) mid_event_destroy(c->ev_t[i]);
