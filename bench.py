@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="disable the per-kernel HIP-event timing")
     ap.add_argument("--bucket-mb", type=int, default=32)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="storage type of activations (bf16 = BASELINE configs[4]); arithmetic is fp32 either way")
+    ap.add_argument("--policy", choices=["fast", "recompute_bn"], default="fast", help="what backward keeps from forward (mi_trainer_set_store_policy)")
     ap.add_argument("--force-dist", action="store_true", help="run the torch.distributed + RCCL path even with one rank (self-test)")
     args = ap.parse_args()
 
@@ -92,6 +94,10 @@ def main():
 
     dims = resnet_dims()
     tr = Trainer(dims, args.batch, lr=1e-4, wd=0.0, b1=0.9, b2=0.999, eps=1e-7, seed=1236, device=local_rank)
+    if args.policy == "recompute_bn":
+        tr.set_store_policy(B.MI_STORE_RECOMPUTE_BN)
+    if args.dtype == "bf16":
+        tr.set_dtype(B.MI_DTYPE_BF16)
     # every rank draws its own slice of the global batch: distinct image/label streams per rank
     from resnet_amd import dp
     tr.source_synthetic(*dp.rank_seeds(rank), pool_batches=2)

@@ -320,6 +320,58 @@ int mi_debug_poison_lds(void);
 int mi_debug_conv_plan(int op, int N, int C, int H, int K, int k, int stride, int out[9]);
 int mi_op_fill_uniform(float *out, size_t n, uint64_t seed, float lo, float hi);
 
+
+/* ---------------- bf16-activation path (BASELINE configs[4]) ----------------
+ * Activations and activation gradients stored as bf16 in the same NCHW tensors (the `float *` fields of Activations then
+ * point at bf16 data, half the bytes), all arithmetic in fp32, convolutions on v_mfma_f32_32x32x16_bf16 with fp32
+ * accumulation; parameters, parameter gradients, Adam state, BN statistics, the stem convolution's own output, the pooled
+ * features and the FC / soft-max head stay fp32.  Structure mirrored: resnet_cudnn_nchw.cu:1196-1211 (NCHW tensors,
+ * TENSOR_OP_MATH_ALLOW_CONVERSION), storage policy of resnet_cudnn_lowmem.cu:2152-2170. */
+enum { MI_DTYPE_F32 = 0, MI_DTYPE_BF16 = 1 };
+/* call after init_trainer and before the first load_new_batch / forward_pass: rebuilds the activation buffers at the new
+ * element size.  Returns 0, or -1 (mi_last_error says why: a layer shape the bf16 kernels do not tile, full-store on). */
+int mi_trainer_set_dtype(Train_ResNet *t, int dtype);
+int mi_trainer_get_dtype(const Train_ResNet *t);
+/* what backward keeps from forward.  FAST (default): per convolution the raw output and the BN(+ReLU) output, per block the
+ * post-ReLU output.  RECOMPUTE_BN: raw convolution outputs, BN statistics and block outputs only; the BN(+ReLU) tensors are
+ * re-derived in backward (resnet_clean.cu:2714, 2753, 2812; resnet_cudnn_lowmem.cu:2303-2313) -- bit-identical gradients,
+ * fewer stored bytes.  FULL: FAST plus x-hat / BN-out / pre-ReLU sums (= mi_trainer_set_full_store, fp32 only). */
+enum { MI_STORE_FAST = 0, MI_STORE_RECOMPUTE_BN = 1, MI_STORE_FULL = 2 };
+int mi_trainer_set_store_policy(Train_ResNet *t, int policy);
+/* bytes of device memory the trainer holds for forward activations (kept for backward) / for everything */
+size_t mi_trainer_activation_bytes(const Train_ResNet *t);
+size_t mi_trainer_device_bytes(const Train_ResNet *t);
+void mi_clear_error(void);
+/* check_errors on demand (resnet.cu:2879-2907): update_parameters no longer blocks to read the NaN / Inf flag of its Adam
+ * launch; it is read at the next forward_pass, or here (waits for the device; dumps id 99999999 and exits like the reference
+ * when set).  Returns 0 when clean. */
+int mi_trainer_check_errors(Train_ResNet *t);
+/* host-only (no GPU needed): the gradient buckets the data-parallel path cuts for a network -- float offsets [from, to) into
+ * the gradient arena in issue order (FC side first).  mi_debug_last_buckets: what the last backwards_pass really issued. */
+int mi_debug_dp_plan(const Dims *d, size_t bucket_bytes, size_t *from, size_t *to, int max);
+size_t mi_debug_arena_floats(const Dims *d);
+int mi_debug_last_buckets(const Train_ResNet *t, size_t *from, size_t *to, int max);
+
+/* typed operator layer: x_dt = storage type of the convolution-side tensors (x, dx), a_dt = of the activation-side tensors
+ * (y, residual, dy, mask_src, gated_out).  Supported pairs: (F32,F32), (BF16,BF16), (F32,BF16). */
+int mi_op_convert(const void *in, int in_dt, void *out, int out_dt, size_t n);
+int mi_bf16_conv_supported(int op, int N, int C, int H, int K, int k, int stride); /* op 0 fwd, 1 dgrad, 2 wgrad */
+int mi_op_conv_fwd_bf16(const void *x_bf16, const float *w_kcrs, void *y_bf16, int N, int C, int H, int K, int k, int stride);
+int mi_op_conv_dgrad_bf16(const float *w_kcrs, const void *dy_bf16, void *dx_bf16, int N, int C, int H, int K, int k, int stride,
+                          int to_add);
+int mi_op_conv_wgrad_bf16(const void *x_bf16, const void *dy_bf16, float *dw_kcrs, int N, int C, int H, int K, int k, int stride);
+int mi_op_bn_fwd_t(const void *x, int x_dt, const float *gamma, const float *beta, const void *residual, float *means, float *vars,
+                   void *y, int a_dt, int N, int C, int H, float eps, int relu);
+int mi_op_bn_apply_t(const void *x, int x_dt, const float *gamma, const float *beta, const void *residual, const float *means,
+                     const float *vars, void *y, int a_dt, int N, int C, int H, float eps, int relu);
+int mi_op_bn_bwd_t(const void *x, int x_dt, const float *gamma, const float *beta, const float *means, const float *vars,
+                   const void *dy, const void *mask_src, void *gated_out, int a_dt, void *dx, float *dgamma, float *dbeta, int N, int C,
+                   int H, float eps, int mask_mode);
+int mi_op_maxpool_fwd_t(const void *x, void *y, int dt, int *max_inds, int N, int C, int H, int k, int stride);
+int mi_op_maxpool_bwd_t(const int *max_inds, const void *dy, void *dx, int dt, int N, int C, int H, int k, int stride);
+int mi_op_avgpool_fwd_t(const void *x, int dt, float *y, int N, int C, int H);
+int mi_op_avgpool_bwd_t(const float *dy, void *dx, int dt, int N, int C, int H);
+
 #ifdef __cplusplus
 }
 #endif

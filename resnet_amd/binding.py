@@ -96,6 +96,8 @@ class Train_ResNet(C.Structure):
 
 MI_SRC_SHARDS, MI_SRC_BUFFER, MI_SRC_SYNTHETIC, MI_SRC_HOST = 0, 1, 2, 3
 MI_LAYOUT_NHWC, MI_LAYOUT_NCHW = 0, 1
+MI_DTYPE_F32, MI_DTYPE_BF16 = 0, 1
+MI_STORE_FAST, MI_STORE_RECOMPUTE_BN, MI_STORE_FULL = 0, 1, 2
 
 # every symbol include/resnet_mi.h declares: name -> (restype, argtypes)
 _i, _f, _vp, _sz, _u64, _cp = C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_uint64, C.c_char_p
@@ -169,6 +171,28 @@ PROTOTYPES = {
     "mi_op_fill_uniform": (_i, [_vp, _sz, _u64, _f, _f]),
     "mi_debug_poison_lds": (_i, []),
     "mi_debug_conv_plan": (_i, [_i] * 7 + [_vp]),
+    "mi_trainer_set_dtype": (_i, [_T, _i]),
+    "mi_trainer_get_dtype": (_i, [_T]),
+    "mi_trainer_set_store_policy": (_i, [_T, _i]),
+    "mi_trainer_activation_bytes": (_sz, [_T]),
+    "mi_trainer_device_bytes": (_sz, [_T]),
+    "mi_clear_error": (None, []),
+    "mi_trainer_check_errors": (_i, [_T]),
+    "mi_debug_dp_plan": (_i, [C.POINTER(Dims), _sz, _vp, _vp, _i]),
+    "mi_debug_arena_floats": (_sz, [C.POINTER(Dims)]),
+    "mi_debug_last_buckets": (_i, [_T, _vp, _vp, _i]),
+    "mi_op_convert": (_i, [_vp, _i, _vp, _i, _sz]),
+    "mi_bf16_conv_supported": (_i, [_i] * 7),
+    "mi_op_conv_fwd_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
+    "mi_op_conv_dgrad_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
+    "mi_op_conv_wgrad_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
+    "mi_op_bn_fwd_t": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i]),
+    "mi_op_bn_apply_t": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i]),
+    "mi_op_bn_bwd_t": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i]),
+    "mi_op_maxpool_fwd_t": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i]),
+    "mi_op_maxpool_bwd_t": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
+    "mi_op_avgpool_fwd_t": (_i, [_vp, _i, _vp, _i, _i, _i]),
+    "mi_op_avgpool_bwd_t": (_i, [_vp, _vp, _i, _i, _i, _i]),
 }
 
 _lib = None

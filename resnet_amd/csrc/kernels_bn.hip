@@ -57,50 +57,55 @@ __device__ __forceinline__ void wel_add_batch(Wel &w, float nb, float bmean, flo
 // grid (C, nsplit): block handles channel c, images n = split, split+nsplit, ...  The (image, position) pairs of the
 // block are ONE flattened index space walked by all 256 threads with four 16-byte loads in flight per thread: a 14x14 or
 // 7x7 plane (49 float4 / 49 floats) no longer leaves 80% of the lanes idle, and a thread merges once per 16 values.
-template <bool VEC>
+template <typename TX, int V>
 __global__ void __launch_bounds__(256)
-bn_stats_kernel(const float *__restrict__ x, float *__restrict__ partial, int N, int C, int P, FastDiv fdPV) {
+bn_stats_kernel(const TX *__restrict__ x, float *__restrict__ partial, int N, int C, int P, FastDiv fdPV) {
     const int c = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
     const int cnt = (N - split + nsplit - 1) / nsplit;            // images of this block
-    constexpr int V = VEC ? 4 : 1;
     const uint32_t PV = (uint32_t)P / V;                          // units per plane
     const uint32_t total = (uint32_t)cnt * PV;
     const size_t img_stride = (size_t)nsplit * C * P;
-    const float *base = x + ((size_t)split * C + c) * P;
+    const TX *base = x + ((size_t)split * C + c) * P;
     Wel w = {0.f, 0.f, 0.f};
-    auto addr = [&](uint32_t idx) -> const float * {
+    auto addr = [&](uint32_t idx) -> const TX * {
         const uint32_t j = fd_div(idx, fdPV), i = idx - j * PV;
         return base + (size_t)j * img_stride + (size_t)i * V;
     };
     uint32_t idx = threadIdx.x;
     for (; idx + 3 * 256 < total; idx += 4 * 256) {
-        if (VEC) {
-            float4 v[4];
+        float v[4][V];
 #pragma unroll
-            for (int u = 0; u < 4; u++) v[u] = *(const float4 *)addr(idx + u * 256);
+        for (int u = 0; u < 4; u++) VecIO<TX, V>::load(addr(idx + u * 256), v[u]);
+        if (V == 1) {
+            const float bm = ((v[0][0] + v[1][0]) + (v[2][0] + v[3][0])) * 0.25f;
+            const float a = v[0][0] - bm, b = v[1][0] - bm, cc = v[2][0] - bm, d = v[3][0] - bm;
+            wel_add_batch(w, 4.f, bm, (a * a + b * b) + (cc * cc + d * d));
+        } else {
             float s = 0.f;
 #pragma unroll
-            for (int u = 0; u < 4; u++) s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
-            const float bm = s * (1.0f / 16.0f);
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int q = 0; q < V; q += 4) s += (v[u][q] + v[u][q + 1]) + (v[u][q + 2] + v[u][q + 3]);
+            const float bm = s * (1.0f / (4.0f * V));
             float m2 = 0.f;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const float a = v[u].x - bm, b = v[u].y - bm, cc = v[u].z - bm, d = v[u].w - bm;
-                m2 += (a * a + b * b) + (cc * cc + d * d);
-            }
-            wel_add_batch(w, 16.f, bm, m2);
-        } else {
-            float v[4];
+            for (int u = 0; u < 4; u++)
 #pragma unroll
-            for (int u = 0; u < 4; u++) v[u] = *addr(idx + u * 256);
-            const float bm = ((v[0] + v[1]) + (v[2] + v[3])) * 0.25f;
-            const float a = v[0] - bm, b = v[1] - bm, cc = v[2] - bm, d = v[3] - bm;
-            wel_add_batch(w, 4.f, bm, (a * a + b * b) + (cc * cc + d * d));
+                for (int q = 0; q < V; q += 4) {
+                    const float a = v[u][q] - bm, b = v[u][q + 1] - bm, cc = v[u][q + 2] - bm, d = v[u][q + 3] - bm;
+                    m2 += (a * a + b * b) + (cc * cc + d * d);
+                }
+            wel_add_batch(w, 4.f * V, bm, m2);
         }
     }
     for (; idx < total; idx += 256) {
-        if (VEC) { const float4 v = *(const float4 *)addr(idx); wel_add4(w, v.x, v.y, v.z, v.w); }
-        else wel_add1(w, *addr(idx));
+        float v[V];
+        VecIO<TX, V>::load(addr(idx), v);
+        if (V == 1) wel_add1(w, v[0]);
+        else {
+#pragma unroll
+            for (int q = 0; q < V; q += 4) wel_add4(w, v[q], v[q + 1], v[q + 2], v[q + 3]);
+        }
     }
     w = wel_wave(w);
     __shared__ Wel sh[4];
@@ -174,13 +179,14 @@ bn_finalize_kernel(const float *__restrict__ partial, int nsplit, int C, float *
 __device__ __forceinline__ float bn_xhat(float x, float mean, float sd) { return (x - mean) / sd; }
 __device__ __forceinline__ float bn_y(float xh, float g, float b) { return fmaf(g, xh, b); }
 
-template <bool VEC>
+// TX: storage type of the convolution output x; TA: of the activation-side tensors (y, residual).  The full-store extras
+// (x_hat, BN output) exist in fp32 only.
+template <typename TX, typename TA, int V>
 __global__ void __launch_bounds__(256)
-bn_apply_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
-                const float *__restrict__ means, const float *__restrict__ vars, const float *__restrict__ residual,
-                float *__restrict__ y, float *__restrict__ xhat_out, float *__restrict__ norm_out, int C, int P,
+bn_apply_kernel(const TX *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
+                const float *__restrict__ means, const float *__restrict__ vars, const TA *__restrict__ residual,
+                TA *__restrict__ y, float *__restrict__ xhat_out, float *__restrict__ norm_out, int C, int P,
                 FastDiv fdP, FastDiv fdC, size_t total, float eps, int relu) {
-    constexpr int V = VEC ? 4 : 1;
     const size_t nvec = total / V;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
         const size_t e = i * V;
@@ -188,12 +194,8 @@ bn_apply_kernel(const float *__restrict__ x, const float *__restrict__ gamma, co
         const uint32_t c = plane - fd_div(plane, fdC) * C;
         const float mean = means[c], sd = sqrtf(vars[c] + eps), g = gamma[c], b = beta[c];
         float v[V], r[V], xh[V], nv[V];
-        if (VEC) { const float4 t = *(const float4 *)(x + e); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-        else v[0] = x[e];
-        if (residual) {
-            if (VEC) { const float4 t = *(const float4 *)(residual + e); r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w; }
-            else r[0] = residual[e];
-        }
+        VecIO<TX, V>::load(x + e, v);
+        if (residual) VecIO<TA, V>::load(residual + e, r);
 #pragma unroll
         for (int q = 0; q < V; q++) {
             xh[q] = bn_xhat(v[q], mean, sd);
@@ -203,31 +205,24 @@ bn_apply_kernel(const float *__restrict__ x, const float *__restrict__ gamma, co
             else if (relu) o = fmaxf(o, 0.f);
             v[q] = o;
         }
-        if (VEC) {
-            *(float4 *)(y + e) = make_float4(v[0], v[1], v[2], v[3]);
-            if (xhat_out) *(float4 *)(xhat_out + e) = make_float4(xh[0], xh[1], xh[2], xh[3]);
-            if (norm_out) *(float4 *)(norm_out + e) = make_float4(nv[0], nv[1], nv[2], nv[3]);
-        } else {
-            y[e] = v[0];
-            if (xhat_out) xhat_out[e] = xh[0];
-            if (norm_out) norm_out[e] = nv[0];
-        }
+        VecIO<TA, V>::store(y + e, v);
+        if (xhat_out) VecIO<float, V>::store(xhat_out + e, xh);
+        if (norm_out) VecIO<float, V>::store(norm_out + e, nv);
     }
 }
 
 // grid (C, nsplit): s1 = sum g, s2 = sum g * x_hat.  Same flattened (image, position) walk as bn_stats_kernel.
 // MASK 3 = MASK 2 (gate dy by mask_src > 0) that also WRITES the gated dy: the identity blocks need relu'(out) * upstream
 // twice more (BN' apply, shortcut addend of the 1x1 dgrad), and producing it here saves the separate ReLU' pass.
-template <int MASK, bool VEC>
+template <int MASK, typename TX, typename TA, int V>
 __global__ void __launch_bounds__(256)
-bn_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ mask_src,
+bn_bwd_reduce_kernel(const TX *__restrict__ x, const TA *__restrict__ dy, const TA *__restrict__ mask_src,
                      const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ means,
-                     const float *__restrict__ vars, float *__restrict__ partial, float *__restrict__ gated, int N, int C, int P,
+                     const float *__restrict__ vars, float *__restrict__ partial, TA *__restrict__ gated, int N, int C, int P,
                      float eps, FastDiv fdPV) {
     const int c = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
     const float mean = means[c], sd = sqrtf(vars[c] + eps), g = gamma[c], b = beta[c];
     const int cnt = (N - split + nsplit - 1) / nsplit;
-    constexpr int V = VEC ? 4 : 1;
     constexpr bool EXT = MASK == 2 || MASK == 3;
     const uint32_t PV = (uint32_t)P / V;
     const uint32_t total = (uint32_t)cnt * PV;
@@ -246,53 +241,43 @@ bn_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ dy, 
         const uint32_t j = fd_div(idx, fdPV), i = idx - j * PV;
         return base + (size_t)j * img_stride + (size_t)i * V;
     };
-    constexpr int U = EXT ? 2 : 4; // loads in flight per thread: U x (2 or 3) x 16 B
+    constexpr int U = (EXT ? 2 : 4) * (V == 8 ? 1 : 1); // units in flight per thread
     uint32_t idx = threadIdx.x;
     for (; idx + (U - 1) * 256 < total; idx += U * 256) {
-        if (VEC) {
-            float4 xv[U], dv[U], mv[U];
-            size_t o[U];
+        float xv[U][V], dv[U][V], mv[U][V];
+        size_t o[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                o[u] = off(idx + u * 256);
-                xv[u] = *(const float4 *)(x + o[u]); dv[u] = *(const float4 *)(dy + o[u]);
-                if (EXT) mv[u] = *(const float4 *)(mask_src + o[u]); else mv[u] = make_float4(1.f, 1.f, 1.f, 1.f);
-            }
+        for (int u = 0; u < U; u++) {
+            o[u] = off(idx + u * 256);
+            VecIO<TX, V>::load(x + o[u], xv[u]);
+            VecIO<TA, V>::load(dy + o[u], dv[u]);
+            if (EXT) VecIO<TA, V>::load(mask_src + o[u], mv[u]);
+            else {
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                float4 gq;
-                gq.x = one(xv[u].x, dv[u].x, mv[u].x); gq.y = one(xv[u].y, dv[u].y, mv[u].y);
-                gq.z = one(xv[u].z, dv[u].z, mv[u].z); gq.w = one(xv[u].w, dv[u].w, mv[u].w);
-                if (MASK == 3) *(float4 *)(gated + o[u]) = gq;
+                for (int q = 0; q < V; q++) mv[u][q] = 1.f;
             }
-        } else {
-            float xv[U], dv[U], mv[U];
-            size_t o[U];
+        }
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                o[u] = off(idx + u * 256);
-                xv[u] = x[o[u]]; dv[u] = dy[o[u]]; mv[u] = EXT ? mask_src[o[u]] : 1.f;
-            }
+        for (int u = 0; u < U; u++) {
+            float gq[V];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const float gq = one(xv[u], dv[u], mv[u]);
-                if (MASK == 3) gated[o[u]] = gq;
-            }
+            for (int q = 0; q < V; q++) gq[q] = one(xv[u][q], dv[u][q], mv[u][q]);
+            if (MASK == 3) VecIO<TA, V>::store(gated + o[u], gq);
         }
     }
     for (; idx < total; idx += 256) {
         const size_t o = off(idx);
-        if (VEC) {
-            const float4 xv = *(const float4 *)(x + o), dv = *(const float4 *)(dy + o);
-            float4 mv = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (EXT) mv = *(const float4 *)(mask_src + o);
-            float4 gq;
-            gq.x = one(xv.x, dv.x, mv.x); gq.y = one(xv.y, dv.y, mv.y); gq.z = one(xv.z, dv.z, mv.z); gq.w = one(xv.w, dv.w, mv.w);
-            if (MASK == 3) *(float4 *)(gated + o) = gq;
-        } else {
-            const float gq = one(x[o], dy[o], EXT ? mask_src[o] : 1.f);
-            if (MASK == 3) gated[o] = gq;
+        float xv[V], dv[V], mv[V], gq[V];
+        VecIO<TX, V>::load(x + o, xv);
+        VecIO<TA, V>::load(dy + o, dv);
+        if (EXT) VecIO<TA, V>::load(mask_src + o, mv);
+        else {
+#pragma unroll
+            for (int q = 0; q < V; q++) mv[q] = 1.f;
         }
+#pragma unroll
+        for (int q = 0; q < V; q++) gq[q] = one(xv[q], dv[q], mv[q]);
+        if (MASK == 3) VecIO<TA, V>::store(gated + o, gq);
     }
     s1 = wave_sum(s1); s2 = wave_sum(s2);
     __shared__ float sh[8];
@@ -318,13 +303,12 @@ bn_bwd_finalize_kernel(float *__restrict__ partial, int nsplit, int C, float *__
     if (lane == 0) { dbeta[c] = s1; dgamma[c] = s2; }
 }
 
-template <int MASK, bool VEC>
+template <int MASK, typename TX, typename TA, int V>
 __global__ void __launch_bounds__(256)
-bn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ mask_src,
+bn_bwd_apply_kernel(const TX *__restrict__ x, const TA *__restrict__ dy, const TA *__restrict__ mask_src,
                     const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ means,
                     const float *__restrict__ vars, const float *__restrict__ dgamma, const float *__restrict__ dbeta,
-                    float *__restrict__ dx, int C, int P, FastDiv fdP, FastDiv fdC, size_t total, float inv_m, float eps) {
-    constexpr int V = VEC ? 4 : 1;
+                    TX *__restrict__ dx, int C, int P, FastDiv fdP, FastDiv fdC, size_t total, float inv_m, float eps) {
     const size_t nvec = total / V;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
         const size_t e = i * V;
@@ -333,14 +317,9 @@ bn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ dy, c
         const float mean = means[c], sd = sqrtf(vars[c] + eps), g = gamma[c], b = beta[c];
         const float k1 = dbeta[c] * inv_m, k2 = dgamma[c] * inv_m, scale = g / sd;
         float xv[V], dv[V], mv[V];
-        if (VEC) {
-            const float4 t = *(const float4 *)(x + e); xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
-            const float4 u = *(const float4 *)(dy + e); dv[0] = u.x; dv[1] = u.y; dv[2] = u.z; dv[3] = u.w;
-            if (MASK == 2) { const float4 m = *(const float4 *)(mask_src + e); mv[0] = m.x; mv[1] = m.y; mv[2] = m.z; mv[3] = m.w; }
-        } else {
-            xv[0] = x[e]; dv[0] = dy[e];
-            if (MASK == 2) mv[0] = mask_src[e];
-        }
+        VecIO<TX, V>::load(x + e, xv);
+        VecIO<TA, V>::load(dy + e, dv);
+        if (MASK == 2) VecIO<TA, V>::load(mask_src + e, mv);
 #pragma unroll
         for (int q = 0; q < V; q++) {
             const float xh = bn_xhat(xv[q], mean, sd);
@@ -350,8 +329,7 @@ bn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ dy, c
             const float gq = on ? dv[q] : 0.f;
             xv[q] = scale * (gq - k1 - xh * k2);
         }
-        if (VEC) *(float4 *)(dx + e) = make_float4(xv[0], xv[1], xv[2], xv[3]);
-        else dx[e] = xv[0];
+        VecIO<TX, V>::store(dx + e, xv);
     }
 }
 
@@ -369,109 +347,190 @@ static int ew_blocks(size_t nvec) {
     return (int)b;
 }
 
+// dtype codes of the storage types: MID_F32 / MID_BF16 (mi_device.h).  Supported (x, activation) pairs: (f32, f32) the
+// reference's path, (bf16, bf16) the bf16-activation path, (f32, bf16) its stem (the 7x7 convolution keeps fp32 tensors).
+static int bn_vec(int x_dt, int a_dt, int P) {
+    if (x_dt == MID_F32 && a_dt == MID_F32) return (P & 3) == 0 ? 4 : 1;
+    return (P & 7) == 0 ? 8 : (P & 3) == 0 ? 4 : 1;
+}
+static bool bn_pair_ok(int x_dt, int a_dt) {
+    return (x_dt == MID_F32 && a_dt == MID_F32) || (x_dt == MID_BF16 && a_dt == MID_BF16) || (x_dt == MID_F32 && a_dt == MID_BF16);
+}
+// expands BODY(TX, TA, V) for the runtime (x_dt, a_dt, vec)
+#define BN_DISPATCH(BODY)                                                                            \
+    do {                                                                                             \
+        if (x_dt == MID_F32 && a_dt == MID_F32) { if (vec == 4) { BODY(float, float, 4); } else { BODY(float, float, 1); } } \
+        else if (x_dt == MID_BF16) { if (vec == 8) { BODY(bf16_t, bf16_t, 8); } else if (vec == 4) { BODY(bf16_t, bf16_t, 4); } else { BODY(bf16_t, bf16_t, 1); } } \
+        else { if (vec == 8) { BODY(float, bf16_t, 8); } else if (vec == 4) { BODY(float, bf16_t, 4); } else { BODY(float, bf16_t, 1); } } \
+    } while (0)
+
+static size_t dt_bytes(int dt) { return dt == MID_BF16 ? 2 : 4; }
+
 extern "C" {
 size_t mid_bn_ws_floats(int C) { return (size_t)C * BN_SPLIT_MAX * 3; }
 
 size_t mid_bn_parts_floats(int N, int K, int Ho) { return (size_t)3 * (size_t)mi_cdiv((long)N * Ho * Ho, 128) * 4 * K; }
 
-static int bn_fwd_apply(hipStream_t st, const float *x, const float *gamma, const float *beta, const float *residual,
-                        const float *means, const float *vars, float *y, float *xhat_out, float *norm_out, int N, int C, int P,
-                        float eps, int relu) {
+static int bn_fwd_apply(hipStream_t st, const void *x, int x_dt, const float *gamma, const float *beta, const void *residual,
+                        const float *means, const float *vars, void *y, int a_dt, float *xhat_out, float *norm_out, int N, int C,
+                        int P, float eps, int relu) {
     const size_t total = (size_t)N * C * P;
     const FastDiv fdP = make_fastdiv(P), fdC = make_fastdiv(C);
-    if ((P & 3) == 0)
-        hipLaunchKernelGGL((bn_apply_kernel<true>), dim3(ew_blocks(total / 4)), dim3(256), 0, st, x, gamma, beta, means,
-                           vars, residual, y, xhat_out, norm_out, C, P, fdP, fdC, total, eps, relu);
-    else
-        hipLaunchKernelGGL((bn_apply_kernel<false>), dim3(ew_blocks(total)), dim3(256), 0, st, x, gamma, beta, means,
-                           vars, residual, y, xhat_out, norm_out, C, P, fdP, fdC, total, eps, relu);
+    const int vec = bn_vec(x_dt, a_dt, P);
+#define APPLY(TX, TA, V)                                                                                                   \
+    hipLaunchKernelGGL((bn_apply_kernel<TX, TA, V>), dim3(ew_blocks(total / V)), dim3(256), 0, st, (const TX *)x, gamma, beta, \
+                       means, vars, (const TA *)residual, (TA *)y, xhat_out, norm_out, C, P, fdP, fdC, total, eps, relu)
+    BN_DISPATCH(APPLY);
+#undef APPLY
     MI_LAUNCH_CHECK("bn_apply_kernel");
     return 0;
+}
+
+static int bn_stats_launch(hipStream_t st, float *ws, const void *x, int x_dt, int N, int C, int P, int ns) {
+    if (x_dt == MID_F32) {
+        if ((P & 3) == 0) hipLaunchKernelGGL((bn_stats_kernel<float, 4>), dim3(C, ns), dim3(256), 0, st, (const float *)x, ws, N, C, P, make_fastdiv(P / 4));
+        else hipLaunchKernelGGL((bn_stats_kernel<float, 1>), dim3(C, ns), dim3(256), 0, st, (const float *)x, ws, N, C, P, make_fastdiv(P));
+    } else {
+        if ((P & 7) == 0) hipLaunchKernelGGL((bn_stats_kernel<bf16_t, 8>), dim3(C, ns), dim3(256), 0, st, (const bf16_t *)x, ws, N, C, P, make_fastdiv(P / 8));
+        else if ((P & 3) == 0) hipLaunchKernelGGL((bn_stats_kernel<bf16_t, 4>), dim3(C, ns), dim3(256), 0, st, (const bf16_t *)x, ws, N, C, P, make_fastdiv(P / 4));
+        else hipLaunchKernelGGL((bn_stats_kernel<bf16_t, 1>), dim3(C, ns), dim3(256), 0, st, (const bf16_t *)x, ws, N, C, P, make_fastdiv(P));
+    }
+    MI_LAUNCH_CHECK("bn_stats_kernel");
+    return 0;
+}
+
+/* statistics only (means / biased vars of x): the recompute policy re-derives activations from them in backward */
+int mid_bn_stats_t(mid_stream s, float *ws, const void *x, int x_dt, float *means, float *vars, int N, int C, int P) {
+    hipStream_t st = (hipStream_t)s;
+    const int ns = bn_nsplit(N, C);
+    if (bn_stats_launch(st, ws, x, x_dt, N, C, P, ns)) return -1;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(mi_cdiv(C, 4)), dim3(256), 0, st, ws, ns, C, means, vars);
+    MI_LAUNCH_CHECK("bn_finalize_kernel");
+    return 0;
+}
+
+/* y from x and GIVEN statistics (no reduction): forward's second half, and the backward-time recomputation of an activation */
+int mid_bn_apply_t(mid_stream s, const void *x, int x_dt, const float *gamma, const float *beta, const void *residual,
+                   const float *means, const float *vars, void *y, int a_dt, int N, int C, int P, float eps, int relu) {
+    if (!bn_pair_ok(x_dt, a_dt)) { mi_record_error("mid_bn_apply_t", "unsupported storage types"); return -2; }
+    hipStream_t st = (hipStream_t)s;
+    mi_prof_begin(st, MI_FAM_BN, 0.0, (double)N * C * P * (dt_bytes(x_dt) + dt_bytes(a_dt) * (residual ? 2 : 1)));
+    const int rc = bn_fwd_apply(st, x, x_dt, gamma, beta, residual, means, vars, y, a_dt, nullptr, nullptr, N, C, P, eps, relu);
+    mi_prof_end(st);
+    return rc;
+}
+
+int mid_bn_fwd_t(mid_stream s, float *ws, const mid_bn_parts *parts, const void *x, int x_dt, const float *gamma, const float *beta,
+                 const void *residual, float *means, float *vars, void *y, int a_dt, float *xhat_out, float *norm_out, int N, int C,
+                 int P, float eps, int relu) {
+    if (!bn_pair_ok(x_dt, a_dt)) { mi_record_error("mid_bn_fwd_t", "unsupported storage types"); return -2; }
+    if ((xhat_out || norm_out) && !(x_dt == MID_F32 && a_dt == MID_F32)) { mi_record_error("mid_bn_fwd_t", "full-store tensors exist in fp32 only"); return -2; }
+    hipStream_t st = (hipStream_t)s;
+    const double xb = (double)N * C * P * dt_bytes(x_dt), ab = (double)N * C * P * dt_bytes(a_dt);
+    if (!parts || parts->nparts <= 0) {
+        const int ns = bn_nsplit(N, C);
+        mi_prof_begin(st, MI_FAM_BN, 0.0, 2 * xb + ab * (residual ? 2 : 1));
+        if (bn_stats_launch(st, ws, x, x_dt, N, C, P, ns)) return -1;
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(mi_cdiv(C, 4)), dim3(256), 0, st, ws, ns, C, means, vars);
+        MI_LAUNCH_CHECK("bn_finalize_kernel");
+    } else {
+        int G = parts->nparts / 64;
+        if (G < 1) G = 1;
+        if (G > BN_SPLIT_MAX) G = BN_SPLIT_MAX;
+        // the statistics pass over x is gone: 2 passes (+1 fused add) instead of 3
+        mi_prof_begin(st, MI_FAM_BN, 0.0, xb + ab * (residual ? 2 : 1));
+        hipLaunchKernelGGL(bn_parts_merge_kernel, dim3(mi_cdiv(C, 64), G), dim3(256), 0, st, parts->buf, parts->nparts, C, ws);
+        MI_LAUNCH_CHECK("bn_parts_merge_kernel");
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(mi_cdiv(C, 4)), dim3(256), 0, st, ws, G, C, means, vars);
+        MI_LAUNCH_CHECK("bn_finalize_kernel");
+    }
+    const int rc = bn_fwd_apply(st, x, x_dt, gamma, beta, residual, means, vars, y, a_dt, xhat_out, norm_out, N, C, P, eps, relu);
+    mi_prof_end(st);
+    return rc;
 }
 
 int mid_bn_fwd(mid_stream s, float *ws, const float *x, const float *gamma, const float *beta, const float *residual,
                float *means, float *vars, float *y, float *xhat_out, float *norm_out, int N, int C, int P, float eps,
                int relu) {
-    hipStream_t st = (hipStream_t)s;
-    const int ns = bn_nsplit(N, C);
-    mi_prof_begin(st, MI_FAM_BN, 0.0, 4.0 * (double)N * C * P * (residual ? 4 : 3));
-    if ((P & 3) == 0) hipLaunchKernelGGL((bn_stats_kernel<true>), dim3(C, ns), dim3(256), 0, st, x, ws, N, C, P, make_fastdiv(P / 4));
-    else hipLaunchKernelGGL((bn_stats_kernel<false>), dim3(C, ns), dim3(256), 0, st, x, ws, N, C, P, make_fastdiv(P));
-    MI_LAUNCH_CHECK("bn_stats_kernel");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(mi_cdiv(C, 4)), dim3(256), 0, st, ws, ns, C, means, vars);
-    MI_LAUNCH_CHECK("bn_finalize_kernel");
-    const int rc = bn_fwd_apply(st, x, gamma, beta, residual, means, vars, y, xhat_out, norm_out, N, C, P, eps, relu);
-    mi_prof_end(st);
-    return rc;
+    return mid_bn_fwd_t(s, ws, nullptr, x, MID_F32, gamma, beta, residual, means, vars, y, MID_F32, xhat_out, norm_out, N, C, P, eps, relu);
 }
 
 int mid_bn_fwd_parts(mid_stream s, float *ws, const mid_bn_parts *parts, const float *x, const float *gamma, const float *beta,
                      const float *residual, float *means, float *vars, float *y, float *xhat_out, float *norm_out, int N,
                      int C, int P, float eps, int relu) {
-    if (!parts || parts->nparts <= 0)
-        return mid_bn_fwd(s, ws, x, gamma, beta, residual, means, vars, y, xhat_out, norm_out, N, C, P, eps, relu);
-    hipStream_t st = (hipStream_t)s;
-    int G = parts->nparts / 64;
-    if (G < 1) G = 1;
-    if (G > BN_SPLIT_MAX) G = BN_SPLIT_MAX;
-    // the statistics pass over x is gone: 2 passes (+1 fused add) instead of 3
-    mi_prof_begin(st, MI_FAM_BN, 0.0, 4.0 * (double)N * C * P * (residual ? 3 : 2));
-    hipLaunchKernelGGL(bn_parts_merge_kernel, dim3(mi_cdiv(C, 64), G), dim3(256), 0, st, parts->buf, parts->nparts, C, ws);
-    MI_LAUNCH_CHECK("bn_parts_merge_kernel");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(mi_cdiv(C, 4)), dim3(256), 0, st, ws, G, C, means, vars);
-    MI_LAUNCH_CHECK("bn_finalize_kernel");
-    const int rc = bn_fwd_apply(st, x, gamma, beta, residual, means, vars, y, xhat_out, norm_out, N, C, P, eps, relu);
-    mi_prof_end(st);
-    return rc;
+    return mid_bn_fwd_t(s, ws, parts, x, MID_F32, gamma, beta, residual, means, vars, y, MID_F32, xhat_out, norm_out, N, C, P, eps, relu);
 }
 
-static int bn_bwd_impl(hipStream_t st, float *ws, const float *x, const float *gamma, const float *beta, const float *means,
-                       const float *vars, const float *dy, const float *mask_src, float *gated_out, float *dx, float *dgamma,
+static int bn_bwd_impl(hipStream_t st, float *ws, const void *x, int x_dt, const float *gamma, const float *beta, const float *means,
+                       const float *vars, const void *dy, const void *mask_src, void *gated_out, int a_dt, void *dx, float *dgamma,
                        float *dbeta, int N, int C, int P, float eps, int mask_mode) {
+    if (!bn_pair_ok(x_dt, a_dt)) { mi_record_error("mid_bn_bwd", "unsupported storage types"); return -2; }
     const int ns = bn_nsplit(N, C);
     dim3 grid(C, ns), block(256);
     if (mask_mode >= 2 && !mask_src) { mi_record_error("mid_bn_bwd", "mask_src missing"); return -2; }
     if (mask_mode == 3 && !gated_out) { mi_record_error("mid_bn_bwd_gate", "gated_out missing"); return -2; }
-    // passes over N*C*P floats: reduce reads x, dy (+mask) (+writes gated); apply reads x, dy (+mask) | x, gated; writes dx
-    mi_prof_begin(st, MI_FAM_BN, 0.0, 4.0 * (double)N * C * P * (mask_mode == 2 ? 7 : mask_mode == 3 ? 7 : 5));
-    const bool rvec = (P & 3) == 0;
-    const FastDiv fdPV = make_fastdiv(rvec ? P / 4 : P);
-#define BWD_REDUCE(M_, V_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<M_, V_>), grid, block, 0, st, x, dy, mask_src, gamma, beta, means, vars, ws, gated_out, N, C, P, eps, fdPV)
-    if (mask_mode == 0) { if (rvec) BWD_REDUCE(0, true); else BWD_REDUCE(0, false); }
-    else if (mask_mode == 1) { if (rvec) BWD_REDUCE(1, true); else BWD_REDUCE(1, false); }
-    else if (mask_mode == 2) { if (rvec) BWD_REDUCE(2, true); else BWD_REDUCE(2, false); }
-    else { if (rvec) BWD_REDUCE(3, true); else BWD_REDUCE(3, false); }
-#undef BWD_REDUCE
+    // passes over N*C*P elements: reduce reads x, dy (+mask) (+writes gated); apply reads x, dy (+mask) | x, gated; writes dx
+    const double xb = (double)N * C * P * dt_bytes(x_dt), ab = (double)N * C * P * dt_bytes(a_dt);
+    mi_prof_begin(st, MI_FAM_BN, 0.0, 3 * xb + ab * (mask_mode >= 2 ? 4 : 2));
+    const int vec = bn_vec(x_dt, a_dt, P);
+    const FastDiv fdPV = make_fastdiv(P / vec);
+#define BWD_REDUCE_M(M_, TX, TA, V)                                                                                         \
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<M_, TX, TA, V>), grid, block, 0, st, (const TX *)x, (const TA *)dy, (const TA *)mask_src, \
+                       gamma, beta, means, vars, ws, (TA *)gated_out, N, C, P, eps, fdPV)
+#define BWD_R0(TX, TA, V) BWD_REDUCE_M(0, TX, TA, V)
+#define BWD_R1(TX, TA, V) BWD_REDUCE_M(1, TX, TA, V)
+#define BWD_R2(TX, TA, V) BWD_REDUCE_M(2, TX, TA, V)
+#define BWD_R3(TX, TA, V) BWD_REDUCE_M(3, TX, TA, V)
+    if (mask_mode == 0) BN_DISPATCH(BWD_R0);
+    else if (mask_mode == 1) BN_DISPATCH(BWD_R1);
+    else if (mask_mode == 2) BN_DISPATCH(BWD_R2);
+    else BN_DISPATCH(BWD_R3);
+#undef BWD_R0
+#undef BWD_R1
+#undef BWD_R2
+#undef BWD_R3
+#undef BWD_REDUCE_M
     MI_LAUNCH_CHECK("bn_bwd_reduce_kernel");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(mi_cdiv(C, 4)), dim3(256), 0, st, ws, ns, C, dgamma, dbeta);
     MI_LAUNCH_CHECK("bn_bwd_finalize_kernel");
     const size_t total = (size_t)N * C * P;
     const FastDiv fdP = make_fastdiv(P), fdC = make_fastdiv(C);
     const float inv_m = 1.0f / (float)((size_t)N * P);
-    const bool vec = (P & 3) == 0;
-    dim3 g2(ew_blocks(vec ? total / 4 : total));
-    const float *dy_apply = mask_mode == 3 ? gated_out : dy; // mode 3: the gated dy is already there, no mask needed
-#define BWD_APPLY(M_, V_)                                                                                                \
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<M_, V_>), g2, block, 0, st, x, dy_apply, mask_src, gamma, beta, means, vars, \
-                       dgamma, dbeta, dx, C, P, fdP, fdC, total, inv_m, eps)
-    if (mask_mode == 0 || mask_mode == 3) { if (vec) BWD_APPLY(0, true); else BWD_APPLY(0, false); }
-    else if (mask_mode == 1) { if (vec) BWD_APPLY(1, true); else BWD_APPLY(1, false); }
-    else { if (vec) BWD_APPLY(2, true); else BWD_APPLY(2, false); }
-#undef BWD_APPLY
+    dim3 g2(ew_blocks(total / vec));
+    const void *dy_apply = mask_mode == 3 ? gated_out : dy; // mode 3: the gated dy is already there, no mask needed
+#define BWD_APPLY_M(M_, TX, TA, V)                                                                                             \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<M_, TX, TA, V>), g2, block, 0, st, (const TX *)x, (const TA *)dy_apply, (const TA *)mask_src, \
+                       gamma, beta, means, vars, dgamma, dbeta, (TX *)dx, C, P, fdP, fdC, total, inv_m, eps)
+#define BWD_A0(TX, TA, V) BWD_APPLY_M(0, TX, TA, V)
+#define BWD_A1(TX, TA, V) BWD_APPLY_M(1, TX, TA, V)
+#define BWD_A2(TX, TA, V) BWD_APPLY_M(2, TX, TA, V)
+    if (mask_mode == 0 || mask_mode == 3) BN_DISPATCH(BWD_A0);
+    else if (mask_mode == 1) BN_DISPATCH(BWD_A1);
+    else BN_DISPATCH(BWD_A2);
+#undef BWD_A0
+#undef BWD_A1
+#undef BWD_A2
+#undef BWD_APPLY_M
     mi_prof_end(st);
     MI_LAUNCH_CHECK("bn_bwd_apply_kernel");
     return 0;
 }
 
+int mid_bn_bwd_t(mid_stream s, float *ws, const void *x, int x_dt, const float *gamma, const float *beta, const float *means,
+                 const float *vars, const void *dy, const void *mask_src, void *gated_out, int a_dt, void *dx, float *dgamma,
+                 float *dbeta, int N, int C, int P, float eps, int mask_mode) {
+    if (mask_mode < 0 || mask_mode > 3) { mi_record_error("mid_bn_bwd", "mask_mode"); return -2; }
+    return bn_bwd_impl((hipStream_t)s, ws, x, x_dt, gamma, beta, means, vars, dy, mask_src, gated_out, a_dt, dx, dgamma, dbeta, N, C, P, eps, mask_mode);
+}
 int mid_bn_bwd(mid_stream s, float *ws, const float *x, const float *gamma, const float *beta, const float *means,
                const float *vars, const float *dy, const float *mask_src, float *dx, float *dgamma, float *dbeta, int N,
                int C, int P, float eps, int mask_mode) {
     if (mask_mode < 0 || mask_mode > 2) { mi_record_error("mid_bn_bwd", "mask_mode"); return -2; }
-    return bn_bwd_impl((hipStream_t)s, ws, x, gamma, beta, means, vars, dy, mask_src, nullptr, dx, dgamma, dbeta, N, C, P, eps, mask_mode);
+    return bn_bwd_impl((hipStream_t)s, ws, x, MID_F32, gamma, beta, means, vars, dy, mask_src, nullptr, MID_F32, dx, dgamma, dbeta, N, C, P, eps, mask_mode);
 }
 int mid_bn_bwd_gate(mid_stream s, float *ws, const float *x, const float *gamma, const float *beta, const float *means,
                     const float *vars, const float *dy, const float *mask_src, float *gated_out, float *dx, float *dgamma,
                     float *dbeta, int N, int C, int P, float eps) {
-    return bn_bwd_impl((hipStream_t)s, ws, x, gamma, beta, means, vars, dy, mask_src, gated_out, dx, dgamma, dbeta, N, C, P, eps, 3);
+    return bn_bwd_impl((hipStream_t)s, ws, x, MID_F32, gamma, beta, means, vars, dy, mask_src, gated_out, MID_F32, dx, dgamma, dbeta, N, C, P, eps, 3);
 }
 }

@@ -945,6 +945,15 @@ int mi_igemm_wgrad(hipStream_t st, mid_workspace *ws, const float *x, const floa
     return 0;
 }
 
+// second stage of a weight gradient whose partials are [split][t][k][c] (also used by the bf16 kernel)
+int mi_igemm_wgrad_reduce(hipStream_t st, const float *part, float *dw, int K, int C, int k, int splits) {
+    const long KC = (long)K * C;
+    if (k == 1) hipLaunchKernelGGL(igemm_wgrad_reduce_kernel<1>, dim3(mi_cdiv(KC, 256)), dim3(256), 0, st, part, dw, KC, splits);
+    else hipLaunchKernelGGL(igemm_wgrad_reduce_kernel<9>, dim3(mi_cdiv(KC, 256)), dim3(256), 0, st, part, dw, KC, splits);
+    MI_LAUNCH_CHECK("igemm_wgrad_reduce_kernel");
+    return 0;
+}
+
 #ifdef IG_STAMP
 extern "C" int mi_debug_igemm_stamps(unsigned long long *dst, int nblocks) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(ig_stamps), sizeof(unsigned long long) * 8 * (size_t)nblocks) == hipSuccess ? 0 : -1;

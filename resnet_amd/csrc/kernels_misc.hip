@@ -5,6 +5,16 @@
 #include "mi_common.hpp"
 #include "mi_device.h"
 
+template <typename T> __device__ __forceinline__ float ldf(const T *p);
+template <> __device__ __forceinline__ float ldf<float>(const float *p) { return *p; }
+template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t *p) { return mi_bf2f(*p); }
+template <typename T> __device__ __forceinline__ void stf(T *p, float v);
+template <> __device__ __forceinline__ void stf<float>(float *p, float v) { *p = v; }
+template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t *p, float v) { *p = mi_f2bf(v); }
+template <typename T> __device__ __forceinline__ void stf2(T *p, float a, float b); // two consecutive elements, 2-element aligned
+template <> __device__ __forceinline__ void stf2<float>(float *p, float a, float b) { *(float2 *)p = make_float2(a, b); }
+template <> __device__ __forceinline__ void stf2<bf16_t>(bf16_t *p, float a, float b) { *(uint32_t *)p = mi_pack_bf2(a, b); }
+
 static int ew_blocks(size_t n, int per = 256) {
     size_t b = (n + per - 1) / per;
     if (b > 16384) b = 16384;
@@ -15,8 +25,9 @@ static int ew_blocks(size_t n, int per = 256) {
 // ---- max pool: window centred at stride*o, OOB skipped, strict '>' (first max wins), init -1024 ----
 // (element counts < 2^32: 32-bit indices and precomputed fast division; the 64-bit % and / of a size_t index cost more
 // than the memory traffic of these kernels)
+template <typename T>
 __global__ void __launch_bounds__(256)
-maxpool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int *__restrict__ idx, uint32_t total, int H, int Ho,
+maxpool_fwd_kernel(const T *__restrict__ x, T *__restrict__ y, int *__restrict__ idx, uint32_t total, int H, int Ho,
                    int k, int stride, FastDiv fdHo) {
     const int half = k / 2;
     for (uint32_t o = blockIdx.x * 256u + threadIdx.x; o < total; o += gridDim.x * 256u) {
@@ -25,7 +36,7 @@ maxpool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int *__re
         const uint32_t nc = fd_div(t, fdHo);
         const int oh = (int)(t - nc * Ho);
         const uint32_t pbase = nc * (uint32_t)(H * H);
-        const float *xp = x + pbase;
+        const T *xp = x + pbase;
         float mv = -1024.f;
         int mi = -1024;
         for (int r = -half; r <= half; r++) {
@@ -34,19 +45,20 @@ maxpool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int *__re
             for (int c = -half; c <= half; c++) {
                 const int iw = stride * ow + c;
                 if (iw < 0 || iw >= H) continue;
-                const float v = xp[ih * H + iw];
+                const float v = ldf<T>(xp + ih * H + iw);
                 if (v > mv) { mv = v; mi = (int)pbase + ih * H + iw; }
             }
         }
-        y[o] = mv;
+        stf<T>(y + o, mv);
         idx[o] = mi;
     }
 }
 // Backward in gather form: each input element looks at the windows that contain it, in the reference's
 // (oh, ow) scan order, and keeps the LAST one whose arg-max it is -- the deterministic execution of the
 // reference's racy plain-store scatter (resnet.cu:493; memset 0 at :2186).
+template <typename T>
 __global__ void __launch_bounds__(256)
-maxpool_bwd_kernel(const int *__restrict__ idx, const float *__restrict__ dy, float *__restrict__ dx, uint32_t total, int H,
+maxpool_bwd_kernel(const int *__restrict__ idx, const T *__restrict__ dy, T *__restrict__ dx, uint32_t total, int H,
                    int Ho, int k, int stride, FastDiv fdH) {
     const int half = k / 2;
     for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
@@ -63,17 +75,18 @@ maxpool_bwd_kernel(const int *__restrict__ idx, const float *__restrict__ dy, fl
         for (int oh = oh_lo; oh <= oh_hi; oh++)
             for (int ow = ow_lo; ow <= ow_hi; ow++) {
                 const uint32_t o = (nc * Ho + oh) * Ho + ow;
-                if (idx[o] == (int)e) v = dy[o];
+                if (idx[o] == (int)e) v = ldf<T>(dy + o);
             }
-        dx[e] = v;
+        stf<T>(dx + e, v);
     }
 }
 
 // The reference's pooling (3x3 window, stride 2, pad 1, even H): one thread per 2x2 input cell (2a..2a+1, 2b..2b+1).  Only
 // the windows (a..a+1, b..b+1) reach the cell -- four (index, dy) pairs serve four outputs (the general kernel above looks up
 // 2.25 windows per element) and the result leaves as two 8-byte stores.  Same "last writer in (oh, ow) scan order" rule.
+template <typename T>
 __global__ void __launch_bounds__(256)
-maxpool_bwd_3x3s2_kernel(const int *__restrict__ idx, const float *__restrict__ dy, float *__restrict__ dx, uint32_t cells, int H,
+maxpool_bwd_3x3s2_kernel(const int *__restrict__ idx, const T *__restrict__ dy, T *__restrict__ dx, uint32_t cells, int H,
                          int Ho, FastDiv fdHo) {
     for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < cells; q += gridDim.x * 256u) {
         const uint32_t t = fd_div(q, fdHo);
@@ -84,7 +97,7 @@ maxpool_bwd_3x3s2_kernel(const int *__restrict__ idx, const float *__restrict__ 
         const bool a1 = a + 1 < Ho, b1 = b + 1 < Ho;
         const uint32_t o00 = obase + a * Ho + b;
         const int i00 = idx[o00], i01 = b1 ? idx[o00 + 1] : -1, i10 = a1 ? idx[o00 + Ho] : -1, i11 = (a1 && b1) ? idx[o00 + Ho + 1] : -1;
-        const float d00 = dy[o00], d01 = b1 ? dy[o00 + 1] : 0.f, d10 = a1 ? dy[o00 + Ho] : 0.f, d11 = (a1 && b1) ? dy[o00 + Ho + 1] : 0.f;
+        const float d00 = ldf<T>(dy + o00), d01 = b1 ? ldf<T>(dy + o00 + 1) : 0.f, d10 = a1 ? ldf<T>(dy + o00 + Ho) : 0.f, d11 = (a1 && b1) ? ldf<T>(dy + o00 + Ho + 1) : 0.f;
         const int e00 = (int)ibase + (2 * a) * H + 2 * b, e01 = e00 + 1, e10 = e00 + H, e11 = e10 + 1;
         float v00 = 0.f, v01 = 0.f, v10 = 0.f, v11 = 0.f;
         // windows in scan order (a,b), (a,b+1), (a+1,b), (a+1,b+1): a later match overwrites an earlier one
@@ -97,25 +110,27 @@ maxpool_bwd_3x3s2_kernel(const int *__restrict__ idx, const float *__restrict__ 
         if (i01 == e11) v11 = d01;
         if (i10 == e11) v11 = d10;
         if (i11 == e11) v11 = d11;
-        *(float2 *)(dx + e00) = make_float2(v00, v01);
-        *(float2 *)(dx + e10) = make_float2(v10, v11);
+        stf2<T>(dx + e00, v00, v01);
+        stf2<T>(dx + e10, v10, v11);
     }
 }
 
 // ---- global average pool: one wave per (n,c) plane ----
-__global__ void __launch_bounds__(256) avgpool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int NC, int P) {
+template <typename T>
+__global__ void __launch_bounds__(256) avgpool_fwd_kernel(const T *__restrict__ x, float *__restrict__ y, int NC, int P) {
     const int lane = threadIdx.x & 63;
     const int plane = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (plane >= NC) return;
-    const float *xp = x + (size_t)plane * P;
+    const T *xp = x + (size_t)plane * P;
     float s = 0.f;
-    for (int i = lane; i < P; i += 64) s += xp[i];
+    for (int i = lane; i < P; i += 64) s += ldf<T>(xp + i);
     s = wave_sum(s);
     if (lane == 0) y[plane] = s / (float)P;
 }
-__global__ void avgpool_bwd_kernel(const float *__restrict__ dy, float *__restrict__ dx, size_t total, int P) {
+template <typename T>
+__global__ void avgpool_bwd_kernel(const float *__restrict__ dy, T *__restrict__ dx, size_t total, int P) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x)
-        dx[e] = dy[e / P] / (float)P;
+        stf<T>(dx + e, dy[e / P] / (float)P);
 }
 
 // ---- elementwise ----
@@ -158,9 +173,12 @@ __global__ void ce_deriv_kernel(const float *__restrict__ pred, const int *__res
 }
 
 // ---- Adam, the three reference kernels fused; same guards (NaN/Inf gradient keeps m,v; NaN/Inf result keeps p) ----
-__global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+// zero_grads: the gradient is cleared where it was finite (the memset of resnet.cu:2972-2978 folded in); a NaN / Inf
+// gradient STAYS in the arena, so that the diagnostic dump of check_errors (resnet.cu:2879-2907) still holds it even
+// though the flag is read only at the next host synchronisation point
+__global__ void adam_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
                             size_t n, float lr, float wd, float b1, float b2, float cur_b1, float cur_b2, float eps,
-                            int *__restrict__ nan_flag) {
+                            int *__restrict__ nan_flag, int zero_grads) {
     bool bad = false;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float gi = g[i], old = p[i];
@@ -171,6 +189,7 @@ __global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, 
             mi = b1 * mi + (1.f - b1) * gd;
             vi = b2 * vi + (1.f - b2) * gd * gd;
             m[i] = mi; v[i] = vi;
+            if (zero_grads) g[i] = 0.f;
         }
         const float ma = mi / (1.f - cur_b1), va = vi / (1.f - cur_b2);
         float np = old - (lr * (ma / (sqrtf(va) + eps)) + wd * old);
@@ -235,42 +254,63 @@ int mid_lds_poison(mid_stream s) {
     MI_LAUNCH_CHECK("lds_poison_kernel");
     return 0;
 }
-int mid_maxpool_fwd(mid_stream s, const float *x, float *y, int *max_inds, int N, int C, int H, int k, int stride) {
+int mid_maxpool_fwd_t(mid_stream s, const void *x, void *y, int dt, int *max_inds, int N, int C, int H, int k, int stride) {
     const int Ho = H / stride;
     const size_t total = (size_t)N * C * Ho * Ho;
     if ((double)N * C * H * H >= 2147483648.0) { mi_record_error("mid_maxpool_fwd", "tensor too large for 32-bit indices"); return -2; }
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)s, x, y, max_inds, (uint32_t)total, H, Ho, k,
-                       stride, make_fastdiv(Ho));
+    if (dt == MID_BF16)
+        hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)s, (const bf16_t *)x, (bf16_t *)y, max_inds,
+                           (uint32_t)total, H, Ho, k, stride, make_fastdiv(Ho));
+    else
+        hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)s, (const float *)x, (float *)y, max_inds,
+                           (uint32_t)total, H, Ho, k, stride, make_fastdiv(Ho));
     MI_LAUNCH_CHECK("maxpool_fwd_kernel");
     return 0;
 }
-int mid_maxpool_bwd(mid_stream s, const int *max_inds, const float *dy, float *dx, int N, int C, int H, int k, int stride) {
+int mid_maxpool_fwd(mid_stream s, const float *x, float *y, int *max_inds, int N, int C, int H, int k, int stride) {
+    return mid_maxpool_fwd_t(s, x, y, MID_F32, max_inds, N, C, H, k, stride);
+}
+} // extern "C"
+template <typename T>
+static int maxpool_bwd_launch(hipStream_t st, const int *max_inds, const T *dy, T *dx, int N, int C, int H, int k, int stride) {
     const int Ho = H / stride;
     const size_t total = (size_t)N * C * H * H;
     if ((double)total >= 2147483648.0) { mi_record_error("mid_maxpool_bwd", "tensor too large for 32-bit indices"); return -2; }
     if (k == 3 && stride == 2 && (H & 1) == 0) {
         const size_t cells = total / 4;
-        hipLaunchKernelGGL(maxpool_bwd_3x3s2_kernel, dim3(ew_blocks(cells)), dim3(256), 0, (hipStream_t)s, max_inds, dy, dx, (uint32_t)cells, H, Ho,
+        hipLaunchKernelGGL(maxpool_bwd_3x3s2_kernel<T>, dim3(ew_blocks(cells)), dim3(256), 0, st, max_inds, dy, dx, (uint32_t)cells, H, Ho,
                            make_fastdiv(Ho));
         MI_LAUNCH_CHECK("maxpool_bwd_3x3s2_kernel");
         return 0;
     }
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)s, max_inds, dy, dx, (uint32_t)total, H, Ho, k,
+    hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(ew_blocks(total)), dim3(256), 0, st, max_inds, dy, dx, (uint32_t)total, H, Ho, k,
                        stride, make_fastdiv(H));
     MI_LAUNCH_CHECK("maxpool_bwd_kernel");
     return 0;
 }
-int mid_avgpool_fwd(mid_stream s, const float *x, float *y, int N, int C, int P) {
-    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(mi_cdiv((long)N * C, 4)), dim3(256), 0, (hipStream_t)s, x, y, N * C, P);
+extern "C" {
+int mid_maxpool_bwd_t(mid_stream s, const int *max_inds, const void *dy, void *dx, int dt, int N, int C, int H, int k, int stride) {
+    if (dt == MID_BF16) return maxpool_bwd_launch<bf16_t>((hipStream_t)s, max_inds, (const bf16_t *)dy, (bf16_t *)dx, N, C, H, k, stride);
+    return maxpool_bwd_launch<float>((hipStream_t)s, max_inds, (const float *)dy, (float *)dx, N, C, H, k, stride);
+}
+int mid_maxpool_bwd(mid_stream s, const int *max_inds, const float *dy, float *dx, int N, int C, int H, int k, int stride) {
+    return mid_maxpool_bwd_t(s, max_inds, dy, dx, MID_F32, N, C, H, k, stride);
+}
+int mid_avgpool_fwd_t(mid_stream s, const void *x, int dt, float *y, int N, int C, int P) {
+    if (dt == MID_BF16) hipLaunchKernelGGL(avgpool_fwd_kernel<bf16_t>, dim3(mi_cdiv((long)N * C, 4)), dim3(256), 0, (hipStream_t)s, (const bf16_t *)x, y, N * C, P);
+    else hipLaunchKernelGGL(avgpool_fwd_kernel<float>, dim3(mi_cdiv((long)N * C, 4)), dim3(256), 0, (hipStream_t)s, (const float *)x, y, N * C, P);
     MI_LAUNCH_CHECK("avgpool_fwd_kernel");
     return 0;
 }
-int mid_avgpool_bwd(mid_stream s, const float *dy, float *dx, int N, int C, int P) {
+int mid_avgpool_fwd(mid_stream s, const float *x, float *y, int N, int C, int P) { return mid_avgpool_fwd_t(s, x, MID_F32, y, N, C, P); }
+int mid_avgpool_bwd_t(mid_stream s, const float *dy, void *dx, int dt, int N, int C, int P) {
     const size_t total = (size_t)N * C * P;
-    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)s, dy, dx, total, P);
+    if (dt == MID_BF16) hipLaunchKernelGGL(avgpool_bwd_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)s, dy, (bf16_t *)dx, total, P);
+    else hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)s, dy, (float *)dx, total, P);
     MI_LAUNCH_CHECK("avgpool_bwd_kernel");
     return 0;
 }
+int mid_avgpool_bwd(mid_stream s, const float *dy, float *dx, int N, int C, int P) { return mid_avgpool_bwd_t(s, dy, dx, MID_F32, N, C, P); }
 int mid_relu_deriv(mid_stream s, const float *x, const float *up, float *out, size_t n) {
     hipLaunchKernelGGL(relu_deriv_kernel, dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, (hipStream_t)s, x, up, out, n);
     MI_LAUNCH_CHECK("relu_deriv_kernel");
@@ -291,9 +331,9 @@ int mid_ce_deriv(mid_stream s, const float *pred, const int *labels, float *d, i
     MI_LAUNCH_CHECK("ce_deriv_kernel");
     return 0;
 }
-int mid_adam(mid_stream s, float *p, const float *g, float *m, float *v, size_t n, float lr, float wd, float b1, float b2,
-             float cur_b1, float cur_b2, float eps, int *nan_flag) {
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)s, p, g, m, v, n, lr, wd, b1, b2, cur_b1, cur_b2, eps, nan_flag);
+int mid_adam(mid_stream s, float *p, float *g, float *m, float *v, size_t n, float lr, float wd, float b1, float b2,
+             float cur_b1, float cur_b2, float eps, int *nan_flag, int zero_grads) {
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)s, p, g, m, v, n, lr, wd, b1, b2, cur_b1, cur_b2, eps, nan_flag, zero_grads);
     MI_LAUNCH_CHECK("adam_kernel");
     return 0;
 }

@@ -16,6 +16,9 @@ extern "C" {
 typedef void *mid_stream;
 typedef void *mid_event;
 
+/* storage type of an activation tensor (parameters, gradients and statistics are always fp32) */
+enum { MID_F32 = 0, MID_BF16 = 1 };
+
 /* ---- runtime ---- */
 int mid_device_count(void);
 int mid_set_device(int dev);
@@ -96,6 +99,21 @@ int mid_conv_wgrad(mid_stream s, mid_workspace *ws, const float *x, const float 
 size_t mid_conv_ws_wt_floats(int C, int K, int k);
 size_t mid_conv_ws_part_floats(int N, int C, int H, int K, int k, int stride);
 
+/* ---- bf16-activation path (kernels_igemm_bf16.hip): x / y / dy / dx are bf16 NCHW, weights fp32 KCRS (rounded to bf16 when
+ * re-laid), weight gradients fp32.  ws->pre_fwd / pre_dgrad point at bf16 k-step tiles when mid_conv_prelayout_all_bf16 made
+ * them; otherwise the call re-lays the weights itself into ws->wt. ---- */
+int mid_bf16_supported(int op, int N, int C, int H, int K, int k, int stride); /* op 0 fwd, 1 dgrad, 2 wgrad */
+size_t mid_bf16_part_floats(int N, int C, int H, int K, int k, int stride);
+int mid_conv_prelayout_all_bf16(mid_stream s, const mid_wt_entry *entries_dev, const int *tile_entry_dev, int ntiles);
+int mid_conv_fwd_bf16(mid_stream s, mid_workspace *ws, const void *x, const float *w, void *y, int N, int C, int H, int K, int k,
+                      int stride, mid_bn_parts *parts);
+int mid_conv_dgrad_bf16(mid_stream s, mid_workspace *ws, const float *w, const void *dy, void *dx, const void *addend, int N, int C,
+                        int H, int K, int k, int stride);
+int mid_conv_wgrad_bf16(mid_stream s, mid_workspace *ws, const void *x, const void *dy, float *dw, int N, int C, int H, int K, int k,
+                        int stride);
+int mid_f32_to_bf16(mid_stream s, const float *in, void *out, size_t n);
+int mid_bf16_to_f32(mid_stream s, const void *in, float *out, size_t n);
+
 /* host-only: route and grid the launch planners choose for a convolution (kernels_igemm.hip); op 0 fwd, 1 dgrad, 2 wgrad */
 int mid_igemm_plan(int op, int N, int C, int H, int K, int k, int stride, int out[9]);
 
@@ -130,6 +148,23 @@ int mid_bn_bwd_gate(mid_stream s, float *stats_ws, const float *x, const float *
                     const float *means, const float *vars, const float *dy, const float *mask_src, float *gated_out,
                     float *dx, float *dgamma, float *dbeta, int N, int C, int P, float eps);
 
+/* the same operators over typed tensors: x_dt = storage type of the convolution output x (and of dx), a_dt = of the
+ * activation-side tensors (y, residual, dy, mask_src, gated_out).  Pairs: (f32,f32), (bf16,bf16), (f32,bf16). */
+int mid_bn_fwd_t(mid_stream s, float *stats_ws, const mid_bn_parts *parts, const void *x, int x_dt, const float *gamma,
+                 const float *beta, const void *residual, float *means, float *vars, void *y, int a_dt, float *xhat_out,
+                 float *norm_out, int N, int C, int P, float eps, int relu);
+int mid_bn_stats_t(mid_stream s, float *stats_ws, const void *x, int x_dt, float *means, float *vars, int N, int C, int P);
+int mid_bn_apply_t(mid_stream s, const void *x, int x_dt, const float *gamma, const float *beta, const void *residual,
+                   const float *means, const float *vars, void *y, int a_dt, int N, int C, int P, float eps, int relu);
+/* mask_mode 0..2 as mid_bn_bwd; 3 = mid_bn_bwd_gate */
+int mid_bn_bwd_t(mid_stream s, float *stats_ws, const void *x, int x_dt, const float *gamma, const float *beta, const float *means,
+                 const float *vars, const void *dy, const void *mask_src, void *gated_out, int a_dt, void *dx, float *dgamma,
+                 float *dbeta, int N, int C, int P, float eps, int mask_mode);
+int mid_maxpool_fwd_t(mid_stream s, const void *x, void *y, int dt, int *max_inds, int N, int C, int H, int k, int stride);
+int mid_maxpool_bwd_t(mid_stream s, const int *max_inds, const void *dy, void *dx, int dt, int N, int C, int H, int k, int stride);
+int mid_avgpool_fwd_t(mid_stream s, const void *x, int dt, float *y, int N, int C, int P);
+int mid_avgpool_bwd_t(mid_stream s, const float *dy, void *dx, int dt, int N, int C, int P);
+
 /* ---- pools, elementwise, loss, optimizer ---- */
 int mid_maxpool_fwd(mid_stream s, const float *x, float *y, int *max_inds, int N, int C, int H, int k, int stride);
 int mid_maxpool_bwd(mid_stream s, const int *max_inds, const float *dy, float *dx, int N, int C, int H, int k,
@@ -141,8 +176,8 @@ int mid_add_relu(mid_stream s, const float *a, const float *b, float *sum_out, f
 int mid_softmax(mid_stream s, const float *x, float *out, int N, int L);
 int mid_ce_deriv(mid_stream s, const float *pred, const int *labels, float *d, int N, int L);
 /* fused updateMeans+updateVars+updateParams (resnet.cu:605-662); sets *nan_flag (device int) on NaN/Inf */
-int mid_adam(mid_stream s, float *p, const float *g, float *m, float *v, size_t n, float lr, float wd, float b1,
-             float b2, float cur_b1, float cur_b2, float eps, int *nan_flag);
+int mid_adam(mid_stream s, float *p, float *g, float *m, float *v, size_t n, float lr, float wd, float b1,
+             float b2, float cur_b1, float cur_b2, float eps, int *nan_flag, int zero_grads);
 int mid_nhwc_to_nchw(mid_stream s, const float *in, float *out, int N, int H, int W, int C);
 int mid_nchw_to_nhwc(mid_stream s, const float *in, float *out, int N, int C, int H, int W);
 /* splitmix64 counter streams on device (synthetic batches): uniform in [lo,hi) / labels mod n_classes */
@@ -156,6 +191,7 @@ int mid_rccl_get_unique_id(void *out, int bytes);
 void *mid_rccl_comm_init(int rank, int world, const void *unique_id, int bytes);
 int mid_rccl_allreduce_sum(void *comm, float *buf, size_t count, mid_stream s);
 void mid_rccl_comm_destroy(void *comm);
+void mid_rccl_comm_abort(void *comm);
 
 #ifdef __cplusplus
 }

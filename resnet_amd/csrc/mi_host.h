@@ -54,7 +54,17 @@ typedef struct MiCtx {
     int *wt_tile_entry_dev;
     int fuse_bn_stats;
     int *nan_flag_dev, *nan_flag_host;
+    int nan_check_pending;       /* update_parameters queued a copy of the flag; read it at the next host sync point */
     int full_store, dump_every, input_reset;
+    int dtype;                   /* MID_F32 | MID_BF16: storage type of activations and activation gradients */
+    int policy;                  /* MI_STORE_FAST | MI_STORE_RECOMPUTE_BN | MI_STORE_FULL */
+    int n_persist;               /* allocs[0 .. n_persist) survive a rebuild of the activation buffers */
+    size_t act_bytes, dev_bytes; /* forward activations kept for backward / every tracked allocation */
+    size_t *alloc_bytes;
+    float *rc_buf[2];            /* RECOMPUTE_BN: scratch for the BN(+ReLU) tensors (forward: consumed at once; backward: re-derived) */
+    float *stem_dx;              /* bf16 mode: the stem convolution's output gradient stays fp32 */
+    int counting_act;
+    int params_dirty;            /* parameters written from the host since the last weight re-layout */
     char *dump_root;
     /* every device allocation of this trainer (freed by destroy_trainer) */
     void **allocs;
@@ -69,6 +79,13 @@ typedef struct MiCtx {
     size_t dp_cursor; /* floats: gradients [dp_cursor, arena_floats) already handed to RCCL */
     mid_event ev_grads, ev_reduced;
     int dp_pending;
+    /* buckets handed to RCCL during the last backwards_pass, in issue order (FC first): Adam of bucket b waits only for
+     * bucket b's event, so the early buckets update while the late ones are still on the wire */
+#define MI_MAX_BUCKETS 64
+    size_t bk_from[MI_MAX_BUCKETS], bk_to[MI_MAX_BUCKETS];
+    mid_event bk_ev[MI_MAX_BUCKETS];
+    int n_buckets;
+    int sync_bn;                 /* cross-replica batch-norm statistics (default off: the reference has none) */
     /* weight-gradient overlap: wgrad(L) runs on the aux stream next to BN'(L-1); joined before the next dgrad */
     int overlap_wgrad, wgrad_pending; /* 0 serial, 1 wgrad next to the following BN' only, 2 free-running (ring of buffers) */
     mid_event ev_bn_done, ev_wgrad_done;
@@ -85,6 +102,10 @@ typedef struct MiCtx {
 } MiCtx;
 
 void *mi_ctx_alloc(MiCtx *c, size_t bytes);
+void mi_params_mark_dirty(void);
+/* buckets the data-parallel path cuts for a network (host-only arithmetic shared with backwards_pass): fills
+ * from[] / to[] (float offsets into the gradient arena, issue order) and returns their number */
+int mi_dp_plan_buckets(const Dims *d, size_t bucket_bytes, size_t *from, size_t *to, int max);
 size_t mi_params_arena_floats(const Params *p);
 float *mi_params_arena_base(const Params *p);
 void mi_dp_reduce_ready(Train_ResNet *t, size_t from_float_offset, int force);

@@ -91,9 +91,67 @@ int mi_op_softmax(const float *x, float *out, int N, int L) { return finish(mid_
 int mi_op_ce_deriv(const float *pred, const int *labels, float *d, int N, int L) { return finish(mid_ce_deriv(mi_global()->compute, pred, labels, d, N, L)); }
 int mi_op_adam(float *p, const float *g, float *m, float *v, size_t n, float lr, float wd, float b1, float b2, float cur_b1,
                float cur_b2, float eps, int *nan_flag_dev) {
-    return finish(mid_adam(mi_global()->compute, p, g, m, v, n, lr, wd, b1, b2, cur_b1, cur_b2, eps, nan_flag_dev));
+    return finish(mid_adam(mi_global()->compute, p, (float *)g, m, v, n, lr, wd, b1, b2, cur_b1, cur_b2, eps, nan_flag_dev, 0));
 }
 int mi_op_nhwc_to_nchw(const float *in, float *out, int N, int H, int W, int C) { return finish(mid_nhwc_to_nchw(mi_global()->compute, in, out, N, H, W, C)); }
 int mi_op_fill_uniform(float *out, size_t n, uint64_t seed, float lo, float hi) { return finish(mid_fill_uniform(mi_global()->compute, out, n, seed, 0, lo, hi)); }
 int mi_debug_poison_lds(void) { return finish(mid_lds_poison(mi_global()->compute)); }
 int mi_debug_conv_plan(int op, int N, int C, int H, int K, int k, int stride, int out[9]) { return mid_igemm_plan(op, N, C, H, K, k, stride, out); }
+
+/* ---- typed operators: activation tensors as bf16 (MI_DTYPE_BF16), arithmetic in fp32 ---- */
+int mi_op_convert(const void *in, int in_dt, void *out, int out_dt, size_t n) {
+    if (in_dt == MID_F32 && out_dt == MID_BF16) return finish(mid_f32_to_bf16(mi_global()->compute, (const float *)in, out, n));
+    if (in_dt == MID_BF16 && out_dt == MID_F32) return finish(mid_bf16_to_f32(mi_global()->compute, in, (float *)out, n));
+    return -2;
+}
+int mi_op_conv_fwd_bf16(const void *x, const float *w, void *y, int N, int C, int H, int K, int k, int stride) {
+    mid_workspace ws;
+    if (ws_make(&ws, (size_t)k * k * C * K, 0)) return -3;
+    int rc = finish(mid_conv_fwd_bf16(mi_global()->compute, &ws, x, w, y, N, C, H, K, k, stride, NULL));
+    ws_free(&ws);
+    return rc;
+}
+int mi_op_conv_dgrad_bf16(const float *w, const void *dy, void *dx, int N, int C, int H, int K, int k, int stride, int to_add) {
+    mid_workspace ws;
+    if (ws_make(&ws, (size_t)k * k * C * K, 0)) return -3;
+    int rc = finish(mid_conv_dgrad_bf16(mi_global()->compute, &ws, w, dy, dx, to_add ? dx : NULL, N, C, H, K, k, stride));
+    ws_free(&ws);
+    return rc;
+}
+int mi_op_conv_wgrad_bf16(const void *x, const void *dy, float *dw, int N, int C, int H, int K, int k, int stride) {
+    mid_workspace ws;
+    if (!mid_bf16_supported(2, N, C, H, K, k, stride)) return -2;
+    if (ws_make(&ws, 0, mid_bf16_part_floats(N, C, H, K, k, stride))) return -3;
+    int rc = finish(mid_conv_wgrad_bf16(mi_global()->compute, &ws, x, dy, dw, N, C, H, K, k, stride));
+    ws_free(&ws);
+    return rc;
+}
+int mi_op_bn_fwd_t(const void *x, int x_dt, const float *gamma, const float *beta, const void *residual, float *means, float *vars,
+                   void *y, int a_dt, int N, int C, int H, float eps, int relu) {
+    float *ws = (float *)mid_malloc(mid_bn_ws_floats(C) * sizeof(float));
+    int rc = finish(mid_bn_fwd_t(mi_global()->compute, ws, NULL, x, x_dt, gamma, beta, residual, means, vars, y, a_dt, NULL, NULL, N, C, H * H, eps, relu));
+    mid_free(ws);
+    return rc;
+}
+int mi_op_bn_bwd_t(const void *x, int x_dt, const float *gamma, const float *beta, const float *means, const float *vars,
+                   const void *dy, const void *mask_src, void *gated_out, int a_dt, void *dx, float *dgamma, float *dbeta, int N, int C,
+                   int H, float eps, int mask_mode) {
+    float *ws = (float *)mid_malloc(mid_bn_ws_floats(C) * sizeof(float));
+    int rc = finish(mid_bn_bwd_t(mi_global()->compute, ws, x, x_dt, gamma, beta, means, vars, dy, mask_src, gated_out, a_dt, dx, dgamma, dbeta, N, C, H * H, eps, mask_mode));
+    mid_free(ws);
+    return rc;
+}
+int mi_op_bn_apply_t(const void *x, int x_dt, const float *gamma, const float *beta, const void *residual, const float *means,
+                     const float *vars, void *y, int a_dt, int N, int C, int H, float eps, int relu) {
+    return finish(mid_bn_apply_t(mi_global()->compute, x, x_dt, gamma, beta, residual, means, vars, y, a_dt, N, C, H * H, eps, relu));
+}
+int mi_op_maxpool_fwd_t(const void *x, void *y, int dt, int *max_inds, int N, int C, int H, int k, int stride) {
+    return finish(mid_maxpool_fwd_t(mi_global()->compute, x, y, dt, max_inds, N, C, H, k, stride));
+}
+int mi_op_maxpool_bwd_t(const int *max_inds, const void *dy, void *dx, int dt, int N, int C, int H, int k, int stride) {
+    return finish(mid_maxpool_bwd_t(mi_global()->compute, max_inds, dy, dx, dt, N, C, H, k, stride));
+}
+int mi_op_avgpool_fwd_t(const void *x, int dt, float *y, int N, int C, int H) { return finish(mid_avgpool_fwd_t(mi_global()->compute, x, dt, y, N, C, H * H)); }
+int mi_op_avgpool_bwd_t(const float *dy, void *dx, int dt, int N, int C, int H) { return finish(mid_avgpool_bwd_t(mi_global()->compute, dy, dx, dt, N, C, H * H)); }
+int mi_bf16_conv_supported(int op, int N, int C, int H, int K, int k, int stride) { return mid_bf16_supported(op, N, C, H, K, k, stride); }
+void mi_clear_error(void) { mid_clear_error(); }

@@ -21,6 +21,7 @@ void mi_record_error(const char *what, const char *detail) {
 extern "C" {
 const char *mid_last_error(void) { return g_err; }
 void mid_clear_error(void) { g_err[0] = 0; }
+void mi_record_host_error(const char *what, const char *detail) { mi_record_error(what, detail); }
 int mid_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -137,7 +138,7 @@ typedef int (*fn_cominit)(void **, int, rcclUniqueId, int);
 typedef int (*fn_allreduce)(const void *, void *, size_t, int, int, void *, hipStream_t);
 typedef int (*fn_destroy)(void *);
 typedef const char *(*fn_errstr)(int);
-static struct { void *h; fn_getuid getuid; fn_cominit init; fn_allreduce allreduce; fn_destroy destroy; fn_errstr errstr; } R;
+static struct { void *h; fn_getuid getuid; fn_cominit init; fn_allreduce allreduce; fn_destroy destroy; fn_destroy abort; fn_errstr errstr; } R;
 static int rccl_load(void) {
     if (R.h) return 0;
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
@@ -147,6 +148,7 @@ static int rccl_load(void) {
     R.init = (fn_cominit)dlsym(R.h, "ncclCommInitRank");
     R.allreduce = (fn_allreduce)dlsym(R.h, "ncclAllReduce");
     R.destroy = (fn_destroy)dlsym(R.h, "ncclCommDestroy");
+    R.abort = (fn_destroy)dlsym(R.h, "ncclCommAbort");
     R.errstr = (fn_errstr)dlsym(R.h, "ncclGetErrorString");
     if (!R.getuid || !R.init || !R.allreduce || !R.destroy) { mi_record_error("dlsym(rccl)", "missing symbol"); return -1; }
     return 0;
@@ -179,4 +181,6 @@ int mid_rccl_allreduce_sum(void *comm, float *buf, size_t count, mid_stream s) {
     return 0;
 }
 void mid_rccl_comm_destroy(void *comm) { if (comm && R.destroy) R.destroy(comm); }
+/* a rank that is about to exit on an error: tears the communicator down so that its peers' collectives fail instead of hanging */
+void mid_rccl_comm_abort(void *comm) { if (comm && R.abort) R.abort(comm); }
 }

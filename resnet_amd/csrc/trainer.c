@@ -37,7 +37,9 @@ int mi_device_count(void) { return mid_device_count(); }
 int mi_set_device(int device) { return mid_set_device(device); }
 const char *mi_last_error(void) { return mid_last_error(); }
 void mi_device_synchronize(void) { mid_device_sync(); }
-void mi_copy_to_device(void *d, const void *s, size_t n) { MiGlobal *g = mi_global(); mid_memcpy_h2d(d, s, n, g->compute); mid_stream_sync(g->compute); }
+static int g_params_dirty = 0; /* any host write into device memory may have been a parameter (weight injection, resume) */
+void mi_params_mark_dirty(void) { g_params_dirty = 1; }
+void mi_copy_to_device(void *d, const void *s, size_t n) { MiGlobal *g = mi_global(); mid_memcpy_h2d(d, s, n, g->compute); mid_stream_sync(g->compute); g_params_dirty = 1; }
 void mi_copy_to_host(void *d, const void *s, size_t n) { MiGlobal *g = mi_global(); mid_memcpy_d2h(d, s, n, g->compute); mid_stream_sync(g->compute); }
 
 void mi_prof_enable(int on) { mid_prof_enable(on); }
@@ -58,10 +60,24 @@ void *mi_ctx_alloc(MiCtx *c, size_t bytes) {
         if (c->n_allocs == c->cap_allocs) {
             c->cap_allocs = c->cap_allocs ? c->cap_allocs * 2 : 256;
             c->allocs = (void **)realloc(c->allocs, sizeof(void *) * c->cap_allocs);
+            c->alloc_bytes = (size_t *)realloc(c->alloc_bytes, sizeof(size_t) * c->cap_allocs);
         }
+        c->alloc_bytes[c->n_allocs] = bytes;
         c->allocs[c->n_allocs++] = p;
+        c->dev_bytes += bytes;
+        if (c->counting_act) c->act_bytes += bytes;
     }
     return p;
+}
+/* frees allocs[first ..): everything a rebuild of the activation buffers replaces */
+static void ctx_free_from(MiCtx *c, int first) {
+    for (int i = first; i < c->n_allocs; i++) { mid_free(c->allocs[i]); c->dev_bytes -= c->alloc_bytes[i]; }
+    c->n_allocs = first;
+}
+/* a launcher that fails leaves unwritten tensors behind: stop like the allocation failure does (the reference's void
+ * API gives its caller nothing to poll) */
+static void ck(int rc, const char *what) {
+    if (rc) { fprintf(stderr, "resnet_mi: %s failed (%d): %s\n", what, rc, mid_last_error()); exit(1); }
 }
 
 /* resnet.cu:666-682 */
@@ -207,22 +223,35 @@ static Cache_BatchNorm *make_cache(MiCtx *c, int input_size, int feature_size, i
     return k;
 }
 static float *falloc(MiCtx *c, size_t n) { return (float *)mi_ctx_alloc(c, n * sizeof(float)); }
+/* an activation tensor of n elements in the trainer's storage type (the struct fields stay `float *`, resnet.h) */
+static float *aalloc(MiCtx *c, size_t n) { return (float *)mi_ctx_alloc(c, n * (c->dtype == MID_BF16 ? 2 : 4)); }
 
-/* init_activations, resnet.cu:1057-1113.  pool != NULL builds the derivative tree over six rolling buffers. */
-static Activations *build_activations(MiCtx *c, const Dims *d, ConvBlock **blocks, int N, float **pool) {
+/* init_activations, resnet.cu:1057-1113.
+ * mode 0: the forward tree.  What it keeps follows c->policy (FAST: raw + BN(+ReLU) output per convolution;
+ *         RECOMPUTE_BN: the BN(+ReLU) tensors are two shared scratch buffers, re-derived in backward).
+ * mode 1: the derivative tree over six rolling buffers (resnet_cudnn_lowmem.cu:2152-2170).
+ * mode 2: the derivative tree with a buffer of its own per tensor, the reference's full mirror (resnet.cu:1151):
+ *         FULL policy, so that a dump of activation_derivs/ holds what its file names say. */
+static Activations *build_activations(MiCtx *c, const Dims *d, ConvBlock **blocks, int N, float **pool, int mode) {
     Activations *a = (Activations *)calloc(1, sizeof(Activations));
     const int f = d->init_conv_filters, Hs = d->input / d->init_conv_stride, Hp = Hs / d->init_maxpool_stride;
     const size_t stem = (size_t)N * f * Hs * Hs, pl = (size_t)N * f * Hp * Hp;
+    const int rc = mode == 0 && c->policy == MI_STORE_RECOMPUTE_BN;
     a->n_conv_blocks = d->n_conv_blocks;
     a->activation_conv_blocks = (Activation_ConvBlock **)calloc(d->n_conv_blocks > 0 ? d->n_conv_blocks : 1, sizeof(void *));
-    if (!pool) {
-        a->init_conv_applied = falloc(c, stem);
+    if (mode == 0) {
+        a->init_conv_applied = falloc(c, stem); /* the 7x7 stem keeps fp32 tensors in every storage type */
         a->norm_init_conv = make_cache(c, (int)stem, f, 1);
-        a->init_conv_activated = falloc(c, stem);
+        a->init_conv_activated = rc ? c->rc_buf[0] : aalloc(c, stem);
         a->max_inds = (int *)mi_ctx_alloc(c, pl * sizeof(int));
-        a->init_convblock_input = falloc(c, pl);
+        a->init_convblock_input = aalloc(c, pl);
+    } else if (mode == 2) {
+        a->init_conv_applied = falloc(c, stem);
+        a->norm_init_conv = make_cache(c, (int)stem, f, 0);
+        a->init_conv_activated = aalloc(c, stem);
+        a->init_convblock_input = aalloc(c, pl);
     } else {
-        a->init_conv_applied = pool[3];   /* B */
+        a->init_conv_applied = c->dtype == MID_BF16 ? c->stem_dx : pool[3]; /* B */
         a->norm_init_conv = make_cache(c, (int)stem, f, 0);
         a->init_conv_activated = pool[2]; /* A */
         a->init_convblock_input = pool[0]; /* U0 */
@@ -236,17 +265,23 @@ static Activations *build_activations(MiCtx *c, const Dims *d, ConvBlock **block
         const size_t rsz = (size_t)N * b->reduced_depth * H * H, ssz = (size_t)N * b->reduced_depth * Ho * Ho,
                      osz = (size_t)N * b->expanded_depth * Ho * Ho;
         const int has_proj = b->projection != NULL;
-        k->norm_post_reduced = make_cache(c, (int)rsz, b->reduced_depth, !pool);
-        k->norm_post_spatial = make_cache(c, (int)ssz, b->reduced_depth, !pool);
-        k->norm_post_expanded = make_cache(c, (int)osz, b->expanded_depth, !pool);
-        if (has_proj) k->norm_post_projection = make_cache(c, (int)osz, b->expanded_depth, !pool);
-        if (!pool) {
-            k->post_reduced = falloc(c, rsz); k->post_reduced_activated = falloc(c, rsz);
-            k->post_spatial = falloc(c, ssz); k->post_spatial_activated = falloc(c, ssz);
-            k->post_expanded = falloc(c, osz);
-            if (has_proj) { k->transformed_residual = falloc(c, osz); k->post_projection_norm_vals = falloc(c, osz); }
-            k->output_activated = falloc(c, osz);
+        k->norm_post_reduced = make_cache(c, (int)rsz, b->reduced_depth, mode == 0);
+        k->norm_post_spatial = make_cache(c, (int)ssz, b->reduced_depth, mode == 0);
+        k->norm_post_expanded = make_cache(c, (int)osz, b->expanded_depth, mode == 0);
+        if (has_proj) k->norm_post_projection = make_cache(c, (int)osz, b->expanded_depth, mode == 0);
+        if (mode == 0) {
+            k->post_reduced = aalloc(c, rsz); k->post_reduced_activated = rc ? c->rc_buf[0] : aalloc(c, rsz);
+            k->post_spatial = aalloc(c, ssz); k->post_spatial_activated = rc ? c->rc_buf[1] : aalloc(c, ssz);
+            k->post_expanded = aalloc(c, osz);
+            if (has_proj) { k->transformed_residual = aalloc(c, osz); k->post_projection_norm_vals = rc ? c->rc_buf[0] : aalloc(c, osz); }
+            k->output_activated = aalloc(c, osz);
             k->output = k->output_activated; /* pre-ReLU sum is not kept unless full-store */
+        } else if (mode == 2) {
+            k->output_activated = aalloc(c, osz); k->output = aalloc(c, osz);
+            k->transformed_residual = has_proj ? aalloc(c, osz) : NULL;
+            k->post_expanded = aalloc(c, osz);
+            k->post_spatial_activated = aalloc(c, ssz); k->post_spatial = aalloc(c, ssz);
+            k->post_reduced_activated = aalloc(c, rsz); k->post_reduced = aalloc(c, rsz);
         } else {
             /* lifetimes inside one block's backward (see backwards_pass): A,B,C,D scratch + alternating U */
             k->output_activated = pool[(i + 1) & 1];
@@ -260,8 +295,10 @@ static Activations *build_activations(MiCtx *c, const Dims *d, ConvBlock **block
         }
         a->activation_conv_blocks[i] = k;
     }
-    a->final_conv_output_pooled = falloc(c, (size_t)N * d->final_depth);
-    if (!pool) a->linear_output = falloc(c, (size_t)N * d->output);
+    if (mode == 0) {
+        a->final_conv_output_pooled = falloc(c, (size_t)N * d->final_depth);
+        a->linear_output = falloc(c, (size_t)N * d->output);
+    } else a->final_conv_output_pooled = falloc(c, (size_t)N * d->final_depth);
     return a;
 }
 
@@ -284,6 +321,7 @@ static void size_workspaces(MiCtx *c, const Dims *d, ConvBlock **blocks, int N) 
 #define LAYER(C_, H_, K_, k_, s_)                                                             \
     do {                                                                                      \
         size_t a_ = mid_conv_ws_wt_floats(C_, K_, k_), b_ = mid_conv_ws_part_floats(N, C_, H_, K_, k_, s_); \
+        if (c->dtype == MID_BF16 && (k_) <= 3) { size_t e_ = mid_bf16_part_floats(N, C_, H_, K_, k_, s_); if (e_ > b_) b_ = e_; } \
         if (a_ > wt) wt = a_;                                                                 \
         if (b_ > part) part = b_;                                                             \
         if ((K_) > maxc) maxc = (K_);                                                         \
@@ -314,20 +352,21 @@ static void size_workspaces(MiCtx *c, const Dims *d, ConvBlock **blocks, int N) 
         c->bn_parts.floats = pf;
         c->bn_parts.buf = pf ? falloc(c, pf) : NULL;
         c->bn_parts.nparts = 0;
-        c->fuse_bn_stats = getenv("RESNET_MI_BNFUSE") ? atoi(getenv("RESNET_MI_BNFUSE")) : 1;
     }
     { /* table of the convolutions whose weights are re-laid once per forward pass (mid_conv_prelayout_all) */
         const int maxn = 4 * d->n_conv_blocks + 1;
         const int prelayout = getenv("RESNET_MI_PRELAYOUT") ? atoi(getenv("RESNET_MI_PRELAYOUT")) : 1; /* 0: each conv re-lays its own */
+        free(c->wt_tab);
         c->wt_tab = (mid_wt_entry *)calloc((size_t)maxn, sizeof(mid_wt_entry));
         c->wt_n = 0; c->wt_tiles = 0;
 #define WT_LAYER(w_, C_, H_, K_, k_, s_)                                                       \
         do {                                                                                       \
             int nf_ = 0, nd_ = 0;                                                                  \
-            if ((w_) && prelayout) mid_conv_prelayout_needs(N, C_, H_, K_, k_, s_, &nf_, &nd_); \
+            if ((w_) && c->dtype == MID_BF16) nf_ = nd_ = 1; /* bf16 k-step tiles, forward and dgrad forms */ \
+            else if ((w_) && prelayout) mid_conv_prelayout_needs(N, C_, H_, K_, k_, s_, &nf_, &nd_); \
             if (nf_ || nd_) {                                                                      \
                 mid_wt_entry *e_ = &c->wt_tab[c->wt_n++];                                          \
-                const size_t n_ = (size_t)(k_) * (k_) * (C_) * (K_);                               \
+                const size_t n_ = ((size_t)(k_) * (k_) * (C_) * (K_)) / (c->dtype == MID_BF16 ? 2 : 1); \
                 e_->w = (w_); e_->K = (K_); e_->C = (C_); e_->T = (k_) * (k_);                     \
                 e_->fwd = nf_ ? falloc(c, n_) : NULL; e_->dgrad = nd_ ? falloc(c, n_) : NULL;      \
                 e_->tile0 = c->wt_tiles; c->wt_tiles += ((C_) / 32) * ((K_) / 32);                 \
@@ -359,50 +398,91 @@ static void size_workspaces(MiCtx *c, const Dims *d, ConvBlock **blocks, int N) 
     }
 }
 
+static MiCtx *ctx_of(Train_ResNet *t) { return (MiCtx *)t->backend_ctx; }
+static void free_activations_host(Activations *a);
+static void add_full_store_extras(Train_ResNet *t);
+/* everything whose size or layout depends on the storage type / store policy: activation trees, derivative buffers,
+ * workspaces, re-laid weight tables.  Called by init_trainer and again by mi_trainer_set_dtype / _set_store_policy. */
+static void build_buffers(Train_ResNet *t) {
+    MiCtx *c = (MiCtx *)t->backend_ctx;
+    Dims *d = t->model->dims;
+    ConvBlock **blocks = t->model->params->conv_blocks;
+    const int N = t->batch_size;
+    const size_t maxe = max_tensor_elems(d, blocks, N);
+    c->act_bytes = 0;
+    c->rc_buf[0] = c->rc_buf[1] = NULL;
+    if (c->policy == MI_STORE_RECOMPUTE_BN) { c->rc_buf[0] = aalloc(c, maxe); c->rc_buf[1] = aalloc(c, maxe); }
+    c->counting_act = 1;
+    t->forward_buffer->activations = build_activations(c, d, blocks, N, NULL, 0);
+    c->counting_act = 0;
+    c->full_store = 0;
+    if (c->policy == MI_STORE_FULL) add_full_store_extras(t);
+    const int f = d->init_conv_filters, Hs = d->input / d->init_conv_stride;
+    c->stem_dx = c->dtype == MID_BF16 ? falloc(c, (size_t)N * f * Hs * Hs) : NULL;
+    float *pool[6];
+    for (int i = 0; i < 6; i++) pool[i] = aalloc(c, maxe);
+    for (int i = 0; i < 6; i++) c->dpool[i] = pool[i];
+    for (int i = 0; i < MI_RING; i++) { c->ring_buf[i] = i < 4 ? pool[2 + i] : aalloc(c, maxe); c->ring_busy[i] = 0; }
+    c->ring_next = 0;
+    t->backprop_buffer->activation_derivs = build_activations(c, d, blocks, N, pool, c->policy == MI_STORE_FULL ? 2 : 1);
+    if (c->policy != MI_STORE_FAST && c->overlap_wgrad > 1) c->overlap_wgrad = 1; /* ring mode re-points derivative tensors */
+    size_workspaces(c, d, blocks, N);
+    mid_stream_sync(G.compute);
+}
+static void drop_buffers(Train_ResNet *t) {
+    MiCtx *c = (MiCtx *)t->backend_ctx;
+    mid_device_sync();
+    ctx_free_from(c, c->n_persist);
+    free_activations_host(t->forward_buffer->activations);
+    free_activations_host(t->backprop_buffer->activation_derivs);
+    t->forward_buffer->activations = NULL; t->backprop_buffer->activation_derivs = NULL;
+    c->wt_n = 0; c->wt_tiles = 0; c->wt_tab_dev = NULL; c->wt_tile_entry_dev = NULL;
+    c->wgrad_pending = 0;
+}
+
 /* resnet.cu:1157-1194 */
 Train_ResNet *init_trainer(ResNet *model, Batch *cur_batch, int batch_size, float learning_rate, float weight_decay,
                            float mean_decay, float var_decay, float eps, int n_epochs, const char *dump_dir) {
     Train_ResNet *t = (Train_ResNet *)calloc(1, sizeof(Train_ResNet));
     MiCtx *c = (MiCtx *)calloc(1, sizeof(MiCtx));
     Dims *d = model->dims;
-    ConvBlock **blocks = model->params->conv_blocks;
     mi_global();
     t->backend_ctx = c;
     t->model = model; t->cur_batch = cur_batch; t->batch_size = batch_size;
     c->dump_every = 1000; /* resnet.cu:2947 */
     c->input_reset = 1;   /* resnet.cu:2981-2982 */
     c->world = 1; c->bucket_bytes = (size_t)32 << 20;
+    c->dtype = MID_F32; c->policy = MI_STORE_FAST;
     c->overlap_wgrad = getenv("RESNET_MI_OVERLAP") ? atoi(getenv("RESNET_MI_OVERLAP")) : 1;
     c->ev_bn_done = mid_event_create(); c->ev_wgrad_done = mid_event_create();
 
+    /* persistent device state: survives a change of storage type / store policy */
     Forward_Buffer *fb = (Forward_Buffer *)calloc(1, sizeof(Forward_Buffer));
-    fb->activations = build_activations(c, d, blocks, batch_size, NULL);
     fb->pred = falloc(c, (size_t)batch_size * d->output); /* reference over-allocates N^2*output (:1126, hazard h4) */
     fb->pred_cpu = (float *)mid_malloc_host((size_t)batch_size * d->output * sizeof(float));
     t->forward_buffer = fb;
-
     Backprop_Buffer *bb = (Backprop_Buffer *)calloc(1, sizeof(Backprop_Buffer));
     bb->output_layer_deriv = falloc(c, (size_t)batch_size * d->output);
     bb->param_derivs = build_params(d, NULL, c);
     bb->prev_means = build_params(d, NULL, c);
     bb->prev_vars = build_params(d, NULL, c);
+    t->backprop_buffer = bb;
     c->arena_floats = mi_params_arena_floats(model->params);
     c->g_arena = mi_params_arena_base(bb->param_derivs);
     c->m_arena = mi_params_arena_base(bb->prev_means);
     c->v_arena = mi_params_arena_base(bb->prev_vars);
-    const size_t maxe = max_tensor_elems(d, blocks, batch_size);
-    float *pool[6];
-    for (int i = 0; i < 6; i++) pool[i] = falloc(c, maxe);
-    for (int i = 0; i < 6; i++) c->dpool[i] = pool[i];
-    for (int i = 0; i < MI_RING; i++) { c->ring_buf[i] = i < 4 ? pool[2 + i] : falloc(c, maxe); c->ring_ev[i] = mid_event_create(); }
-    bb->activation_derivs = build_activations(c, d, blocks, batch_size, pool);
-    t->backprop_buffer = bb;
-    size_workspaces(c, d, blocks, batch_size);
     c->nan_flag_dev = (int *)mi_ctx_alloc(c, sizeof(int));
     c->nan_flag_host = (int *)mid_malloc_host(sizeof(int));
+    *c->nan_flag_host = 0;
     mid_memset(c->nan_flag_dev, 0, sizeof(int), G.compute);
+    c->n_persist = c->n_allocs;
+    for (int i = 0; i < MI_RING; i++) c->ring_ev[i] = mid_event_create();
     c->ev_grads = mid_event_create(); c->ev_reduced = mid_event_create();
     for (int i = 0; i < 6; i++) c->ev_t[i] = mid_event_create();
+    for (int i = 0; i < MI_MAX_BUCKETS; i++) c->bk_ev[i] = mid_event_create();
+    c->fuse_bn_stats = getenv("RESNET_MI_BNFUSE") ? atoi(getenv("RESNET_MI_BNFUSE")) : 1;
+
+    build_buffers(t);
 
     t->learning_rate = learning_rate; t->weight_decay = weight_decay;
     t->base_mean_decay = mean_decay; t->base_var_decay = var_decay;
@@ -422,13 +502,11 @@ Train_ResNet *init_trainer_cudnn_abi(ResNet *model, Batch *cur_batch, int batch_
     return init_trainer(model, cur_batch, batch_size, learning_rate, weight_decay, mean_decay, var_decay, eps, n_epochs, dump_dir);
 }
 
-static MiCtx *ctx_of(Train_ResNet *t) { return (MiCtx *)t->backend_ctx; }
-
-void mi_trainer_set_full_store(Train_ResNet *t, int on) {
+/* FULL policy: x-hat, BN output and pre-ReLU sums as the reference stores them (dump parity; fp32 only) */
+static void add_full_store_extras(Train_ResNet *t) {
     MiCtx *c = ctx_of(t);
-    if (!on || c->full_store) { c->full_store = on; return; }
-    c->full_store = 1;
     Activations *a = t->forward_buffer->activations;
+    c->counting_act = 1;
 #define EXTRA(cache) do { (cache)->normalized_temp = falloc(c, (cache)->input_size); (cache)->normalized = falloc(c, (cache)->input_size); } while (0)
     EXTRA(a->norm_init_conv);
     for (int i = 0; i < a->n_conv_blocks; i++) {
@@ -439,18 +517,76 @@ void mi_trainer_set_full_store(Train_ResNet *t, int on) {
         k->output = falloc(c, k->norm_post_expanded->input_size);
     }
 #undef EXTRA
+    c->counting_act = 0;
+    c->full_store = 1;
+}
+/* every convolution of the bottleneck blocks must tile for the bf16 kernels (the stem stays on the fp32 path) */
+static int bf16_net_supported(const Train_ResNet *t, char *why, size_t whylen) {
+    const Dims *d = t->model->dims;
+    ConvBlock **blocks = t->model->params->conv_blocks;
+    const int N = t->batch_size;
+    for (int i = 0; i < d->n_conv_blocks; i++) {
+        const ConvBlock *b = blocks[i];
+        const int H = b->incoming_spatial_dim;
+        const int L[4][5] = {{b->incoming_filters, H, b->reduced_depth, 1, 1},
+                             {b->reduced_depth, H, b->reduced_depth, 3, b->stride},
+                             {b->reduced_depth, H / b->stride, b->expanded_depth, 1, 1},
+                             {b->incoming_filters, H, b->expanded_depth, b->stride == 2 ? 3 : 1, b->stride}};
+        for (int j = 0; j < (b->projection ? 4 : 3); j++)
+            for (int op = 0; op < 3; op++)
+                if (!mid_bf16_supported(op, N, L[j][0], L[j][1], L[j][2], L[j][3], L[j][4])) {
+                    snprintf(why, whylen, "block %d conv %d (C=%d H=%d K=%d k=%d s=%d) op %d does not tile for the bf16 kernels", i, j,
+                             L[j][0], L[j][1], L[j][2], L[j][3], L[j][4], op);
+                    return 0;
+                }
+    }
+    return 1;
+}
+void mi_record_host_error(const char *what, const char *detail);
+int mi_trainer_set_store_policy(Train_ResNet *t, int policy) {
+    MiCtx *c = ctx_of(t);
+    if (policy < MI_STORE_FAST || policy > MI_STORE_FULL) { mi_record_host_error("mi_trainer_set_store_policy", "unknown policy"); return -1; }
+    if (policy == MI_STORE_FULL && c->dtype != MID_F32) { mi_record_host_error("mi_trainer_set_store_policy", "the FULL policy (x-hat / BN-out / pre-ReLU sums) exists in fp32 only"); return -1; }
+    if (policy == c->policy) return 0;
+    drop_buffers(t);
+    c->policy = policy;
+    build_buffers(t);
+    return 0;
+}
+void mi_trainer_set_full_store(Train_ResNet *t, int on) { (void)mi_trainer_set_store_policy(t, on ? MI_STORE_FULL : MI_STORE_FAST); }
+int mi_trainer_set_dtype(Train_ResNet *t, int dtype) {
+    MiCtx *c = ctx_of(t);
+    if (dtype != MID_F32 && dtype != MID_BF16) { mi_record_host_error("mi_trainer_set_dtype", "unknown dtype"); return -1; }
+    if (dtype == c->dtype) return 0;
+    if (dtype == MID_BF16) {
+        char why[256];
+        if (c->policy == MI_STORE_FULL) { mi_record_host_error("mi_trainer_set_dtype", "the FULL store policy exists in fp32 only"); return -1; }
+        if (!bf16_net_supported(t, why, sizeof why)) { mi_record_host_error("mi_trainer_set_dtype", why); return -1; }
+    }
+    drop_buffers(t);
+    c->dtype = dtype;
+    build_buffers(t);
+    return 0;
+}
+int mi_trainer_get_dtype(const Train_ResNet *t) { return ((MiCtx *)t->backend_ctx)->dtype; }
+size_t mi_trainer_activation_bytes(const Train_ResNet *t) { return ((MiCtx *)t->backend_ctx)->act_bytes; }
+size_t mi_trainer_device_bytes(const Train_ResNet *t) {
+    const MiCtx *c = (MiCtx *)t->backend_ctx;
+    return c->dev_bytes + c->arena_floats * sizeof(float); /* + the parameter arena (owned by the model) */
 }
 void mi_trainer_set_dump_every(Train_ResNet *t, int every) { ctx_of(t)->dump_every = every; }
 void mi_trainer_set_overlap(Train_ResNet *t, int mode) {
     MiCtx *c = ctx_of(t);
     mid_stream_sync(G.aux); mid_stream_sync(G.compute);
     c->overlap_wgrad = mode < 0 ? 0 : mode > 2 ? 2 : mode;
+    if (c->policy != MI_STORE_FAST && c->overlap_wgrad > 1) c->overlap_wgrad = 1; /* the ring re-points derivative tensors */
     c->wgrad_pending = 0;
     for (int i = 0; i < MI_RING; i++) c->ring_busy[i] = 0;
     if (c->overlap_wgrad != 2) { /* back to the fixed aliasing of build_activations */
         Activations *da = t->backprop_buffer->activation_derivs;
         float **pool = c->dpool;
-        da->init_conv_applied = pool[3]; da->init_conv_activated = pool[2];
+        if (c->policy == MI_STORE_FULL) return; /* every derivative tensor has a buffer of its own */
+        da->init_conv_applied = c->dtype == MID_BF16 ? c->stem_dx : pool[3]; da->init_conv_activated = pool[2];
         for (int i = 0; i < da->n_conv_blocks; i++) {
             Activation_ConvBlock *k = da->activation_conv_blocks[i];
             k->output = pool[5];
@@ -483,19 +619,47 @@ static const mid_wt_entry *wt_lookup(const MiCtx *c, const float *w) {
     return NULL;
 }
 
-/* conv + BN (+ReLU | +residual+ReLU): prepareAndDoConvolution + prepareAndDoBatchNormAndActivate     */
+/* every implicit-GEMM layer's weights in the layouts forward and dgrad want, one launch (they hold until the parameters
+ * change: update_parameters, or a host write -- mi_copy_to_device / overwrite_model_params set the dirty flag) */
+static void relayout_weights(MiCtx *c) {
+    if (c->dtype == MID_BF16) ck(mid_conv_prelayout_all_bf16(G.compute, c->wt_tab_dev, c->wt_tile_entry_dev, c->wt_tiles), "weight re-layout (bf16)");
+    else ck(mid_conv_prelayout_all(G.compute, c->wt_tab_dev, c->wt_tile_entry_dev, c->wt_tiles), "weight re-layout");
+    g_params_dirty = 0;
+}
+/* the NaN / Inf flag update_parameters queued a copy of; valid after any later synchronisation of the compute stream
+ * (check_errors, resnet.cu:2879-2907: dump id 99999999 and exit; offending gradients are still in the arena, the Adam
+ * kernel clears only finite ones) */
+void dump_trainer(int dump_id, Train_ResNet *trainer, const char *special_dir);
+static void poll_nan_flag(Train_ResNet *t) {
+    MiCtx *c = ctx_of(t);
+    if (!c->nan_check_pending) return;
+    c->nan_check_pending = 0;
+    if (*c->nan_flag_host) {
+        printf("ERROR: nan or inf found in parameters, gradients or Adam moments\n");
+        printf("Dumping data to id=99999999 and exiting...\n");
+        dump_trainer(99999999, t, t->dump_dir);
+        if (c->comm) mid_rccl_comm_abort(c->comm); /* do not leave the peers waiting in a collective */
+        exit(1);
+    }
+}
+
+/* conv + BN (+ReLU | +residual+ReLU): prepareAndDoConvolution + prepareAndDoBatchNormAndActivate.
+ * stem: the 7x7 convolution keeps fp32 input / output in every storage type; only its BN output is an activation tensor */
 static void unit_fwd(Train_ResNet *t, const float *in, const float *w, const BatchNorm *bn, Cache_BatchNorm *cache,
                      float *conv_out, float *act_out, const float *residual, int C, int H, int K, int k, int stride,
-                     int relu) {
+                     int relu, int stem) {
     MiCtx *c = ctx_of(t);
     const int N = t->batch_size, Ho = H / stride;
+    const int bf = c->dtype == MID_BF16 && !stem;
     /* the convolution leaves per-tile (count, mean, M2) partials of its output: BN reads the tensor twice, not three times */
     const mid_wt_entry *we = wt_lookup(c, w);
+    mid_bn_parts *parts = (c->fuse_bn_stats || bf) ? &c->bn_parts : NULL;
     c->ws.pre_fwd = we ? we->fwd : NULL; /* re-laid at the start of this forward pass */
-    mid_conv_fwd_stats(G.compute, &c->ws, in, w, conv_out, N, C, H, K, k, stride, c->fuse_bn_stats ? &c->bn_parts : NULL);
+    if (bf) ck(mid_conv_fwd_bf16(G.compute, &c->ws, in, w, conv_out, N, C, H, K, k, stride, parts), "convolution forward (bf16)");
+    else ck(mid_conv_fwd_stats(G.compute, &c->ws, in, w, conv_out, N, C, H, K, k, stride, parts), "convolution forward");
     c->ws.pre_fwd = NULL;
-    mid_bn_fwd_parts(G.compute, c->bn_ws, c->fuse_bn_stats ? &c->bn_parts : NULL, conv_out, bn->gamma, bn->beta, residual,
-                     cache->means, cache->vars, act_out, cache->normalized_temp, cache->normalized, N, K, Ho * Ho, t->eps, relu);
+    ck(mid_bn_fwd_t(G.compute, c->bn_ws, parts, conv_out, bf ? MID_BF16 : MID_F32, bn->gamma, bn->beta, residual, cache->means, cache->vars,
+                    act_out, c->dtype, cache->normalized_temp, cache->normalized, N, K, Ho * Ho, t->eps, relu), "batch norm forward");
 }
 
 /* resnet.cu:1526-1775 */
@@ -506,49 +670,48 @@ void forward_pass(Train_ResNet *t) {
     Activations *a = t->forward_buffer->activations;
     const int N = t->batch_size, f = d->init_conv_filters;
     mid_event_record(c->ev_t[0], G.compute);
-    /* every implicit-GEMM layer's weights in the layouts forward and dgrad want, one launch (they hold until the next
-     * update_parameters; a caller that rewrites parameters between forward_pass and backwards_pass is not supported) */
-    mid_conv_prelayout_all(G.compute, c->wt_tab_dev, c->wt_tile_entry_dev, c->wt_tiles);
+    relayout_weights(c);
     unit_fwd(t, t->cur_batch->images, p->init_conv_layer, p->norm_init_conv, a->norm_init_conv, a->init_conv_applied,
-             a->init_conv_activated, NULL, 3, d->input, f, d->init_kernel_dim, d->init_conv_stride, 1);
+             a->init_conv_activated, NULL, 3, d->input, f, d->init_kernel_dim, d->init_conv_stride, 1, 1);
     const int Hs = d->input / d->init_conv_stride;
-    mid_maxpool_fwd(G.compute, a->init_conv_activated, a->init_convblock_input, a->max_inds, N, f, Hs, d->init_maxpool_dim,
-                    d->init_maxpool_stride);
+    ck(mid_maxpool_fwd_t(G.compute, a->init_conv_activated, a->init_convblock_input, c->dtype, a->max_inds, N, f, Hs, d->init_maxpool_dim,
+                         d->init_maxpool_stride), "max-pool forward");
     const float *bin = a->init_convblock_input;
     for (int i = 0; i < d->n_conv_blocks; i++) {
         const ConvBlock *b = p->conv_blocks[i];
         Activation_ConvBlock *k = a->activation_conv_blocks[i];
         const int H = b->incoming_spatial_dim, Ho = H / b->stride;
         unit_fwd(t, bin, b->depth_reduction, b->norm_depth_reduction, k->norm_post_reduced, k->post_reduced,
-                 k->post_reduced_activated, NULL, b->incoming_filters, H, b->reduced_depth, 1, 1, 1);
+                 k->post_reduced_activated, NULL, b->incoming_filters, H, b->reduced_depth, 1, 1, 1, 0);
         unit_fwd(t, k->post_reduced_activated, b->spatial, b->norm_spatial, k->norm_post_spatial, k->post_spatial,
-                 k->post_spatial_activated, NULL, b->reduced_depth, H, b->reduced_depth, 3, b->stride, 1);
+                 k->post_spatial_activated, NULL, b->reduced_depth, H, b->reduced_depth, 3, b->stride, 1, 0);
         const float *res = bin;
         if (b->projection) { /* resnet.cu:1685-1704 */
             unit_fwd(t, bin, b->projection, b->norm_projection, k->norm_post_projection, k->transformed_residual,
                      k->post_projection_norm_vals, NULL, b->incoming_filters, H, b->expanded_depth, b->stride == 2 ? 3 : 1,
-                     b->stride, 0);
+                     b->stride, 0, 0);
             res = k->post_projection_norm_vals;
         }
         if (!c->full_store) { /* BN(expanded) + addVec + doActivation in one kernel (:1670, :1717, :1723) */
             unit_fwd(t, k->post_spatial_activated, b->depth_expansion, b->norm_expansion, k->norm_post_expanded,
-                     k->post_expanded, k->output_activated, res, b->reduced_depth, Ho, b->expanded_depth, 1, 1, 0);
+                     k->post_expanded, k->output_activated, res, b->reduced_depth, Ho, b->expanded_depth, 1, 1, 0, 0);
         } else {
             unit_fwd(t, k->post_spatial_activated, b->depth_expansion, b->norm_expansion, k->norm_post_expanded,
-                     k->post_expanded, k->post_expanded_norm_vals, NULL, b->reduced_depth, Ho, b->expanded_depth, 1, 1, 0);
-            mid_add_relu(G.compute, k->post_expanded_norm_vals, res, k->output, k->output_activated,
-                         (size_t)N * b->expanded_depth * Ho * Ho);
+                     k->post_expanded, k->post_expanded_norm_vals, NULL, b->reduced_depth, Ho, b->expanded_depth, 1, 1, 0, 0);
+            ck(mid_add_relu(G.compute, k->post_expanded_norm_vals, res, k->output, k->output_activated,
+                            (size_t)N * b->expanded_depth * Ho * Ho), "add + ReLU");
         }
         bin = k->output_activated;
     }
     const ConvBlock *last = p->conv_blocks[d->n_conv_blocks - 1];
     const int Hl = last->incoming_spatial_dim; /* resnet.cu:1732 */
-    mid_avgpool_fwd(G.compute, bin, a->final_conv_output_pooled, N, d->final_depth, Hl * Hl);
-    mid_gemm_nn(G.compute, a->final_conv_output_pooled, p->fully_connected, a->linear_output, N, d->final_depth, d->output);
-    mid_softmax(G.compute, a->linear_output, t->forward_buffer->pred, N, d->output);
+    ck(mid_avgpool_fwd_t(G.compute, bin, c->dtype, a->final_conv_output_pooled, N, d->final_depth, Hl * Hl), "average pool");
+    ck(mid_gemm_nn(G.compute, a->final_conv_output_pooled, p->fully_connected, a->linear_output, N, d->final_depth, d->output), "FC forward");
+    ck(mid_softmax(G.compute, a->linear_output, t->forward_buffer->pred, N, d->output), "soft-max");
     mid_event_record(c->ev_t[1], G.compute);
     mid_memcpy_d2h(t->forward_buffer->pred_cpu, t->forward_buffer->pred, (size_t)N * d->output * sizeof(float), G.compute);
     mid_stream_sync(G.compute); /* the reference's blocking cudaMemcpy (:1774) */
+    poll_nan_flag(t);           /* the previous update's flag copy has landed by now */
 }
 
 /* resnet.cu:3363-3383 */
@@ -582,41 +745,55 @@ static float *ring_take(MiCtx *c, int *slot) {
     if (slot) *slot = i;
     return c->ring_buf[i];
 }
+/* typed launch helpers: the bottleneck convolutions run on the bf16 kernels in bf16 mode, the stem always on the fp32 path */
+static void conv_dgrad_t(Train_ResNet *t, const float *w, const float *dy, float *dx, const float *addend, int C, int H, int K, int k,
+                         int stride) {
+    MiCtx *c = ctx_of(t);
+    const mid_wt_entry *we = wt_lookup(c, w);
+    c->ws.pre_dgrad = we ? we->dgrad : NULL;
+    if (c->dtype == MID_BF16) ck(mid_conv_dgrad_bf16(G.compute, &c->ws, w, dy, dx, addend, t->batch_size, C, H, K, k, stride), "convolution dgrad (bf16)");
+    else ck(mid_conv_dgrad(G.compute, &c->ws, w, dy, dx, addend, t->batch_size, C, H, K, k, stride), "convolution dgrad");
+    c->ws.pre_dgrad = NULL;
+}
+static void conv_wgrad_t(Train_ResNet *t, mid_stream st, const float *x, const float *dy, float *dw, int C, int H, int K, int k, int stride,
+                         int stem) {
+    MiCtx *c = ctx_of(t);
+    if (c->dtype == MID_BF16 && !stem) ck(mid_conv_wgrad_bf16(st, &c->ws, x, dy, dw, t->batch_size, C, H, K, k, stride), "convolution wgrad (bf16)");
+    else ck(mid_conv_wgrad(st, &c->ws, x, dy, dw, t->batch_size, C, H, K, k, stride), "convolution wgrad");
+}
 /* d_slot: ring slot holding d_conv_out (mode 2), -1 otherwise */
 static void unit_bwd(Train_ResNet *t, const float *in, const float *w, const BatchNorm *bn, const Cache_BatchNorm *cache,
                      const BatchNorm *dbn, const float *conv_out, const float *dy, const float *mask_src, int mask_mode,
                      float *gated_out, float *d_conv_out, int d_slot, float *dx, const float *addend, float *dw, int C, int H, int K, int k,
-                     int stride) {
+                     int stride, int stem) {
     MiCtx *c = ctx_of(t);
     const int N = t->batch_size, Ho = H / stride;
-    /* BN' of this unit (HBM-bound) runs next to earlier units' weight gradients (FMA-bound, low-priority aux stream) */
-    if (mask_mode == 3) /* ReLU' of the block output fused in, and its product with the upstream gradient kept (gated_out) */
-        mid_bn_bwd_gate(G.compute, c->bn_ws, conv_out, bn->gamma, bn->beta, cache->means, cache->vars, dy, mask_src, gated_out,
-                        d_conv_out, dbn->gamma, dbn->beta, N, K, Ho * Ho, t->eps);
-    else
-        mid_bn_bwd(G.compute, c->bn_ws, conv_out, bn->gamma, bn->beta, cache->means, cache->vars, dy, mask_src, d_conv_out,
-                   dbn->gamma, dbn->beta, N, K, Ho * Ho, t->eps, mask_mode);
+    const int x_dt = (c->dtype == MID_BF16 && !stem) ? MID_BF16 : MID_F32;
+    /* BN' of this unit (HBM-bound) runs next to earlier units' weight gradients (FMA-bound, low-priority aux stream);
+     * mask_mode 3: ReLU' of the block output fused in, and its product with the upstream gradient kept (gated_out) */
+    ck(mid_bn_bwd_t(G.compute, c->bn_ws, conv_out, x_dt, bn->gamma, bn->beta, cache->means, cache->vars, dy, mask_src, gated_out, c->dtype,
+                    d_conv_out, dbn->gamma, dbn->beta, N, K, Ho * Ho, t->eps, mask_mode), "batch norm backward");
     if (c->overlap_wgrad == 2 && d_slot >= 0) {
         /* d_conv_out is final once BN' is: the weight gradient may start now and run for as long as the slot lives */
         mid_event_record(c->ev_bn_done, G.compute);
         mid_stream_wait_event(G.aux, c->ev_bn_done);
-        mid_conv_wgrad(G.aux, &c->ws, in, d_conv_out, dw, N, C, H, K, k, stride);
+        conv_wgrad_t(t, G.aux, in, d_conv_out, dw, C, H, K, k, stride, stem);
         mid_event_record(c->ring_ev[d_slot], G.aux);
         c->ring_busy[d_slot] = 1;
         mid_event_record(c->ev_wgrad_done, G.aux);
         c->wgrad_pending = 1;
-        if (dx) { const mid_wt_entry *we = wt_lookup(c, w); c->ws.pre_dgrad = we ? we->dgrad : NULL; mid_conv_dgrad(G.compute, &c->ws, w, d_conv_out, dx, addend, N, C, H, K, k, stride); c->ws.pre_dgrad = NULL; }
+        if (dx) conv_dgrad_t(t, w, d_conv_out, dx, addend, C, H, K, k, stride);
         return;
     }
     join_wgrad(c);
-    if (dx) { const mid_wt_entry *we = wt_lookup(c, w); c->ws.pre_dgrad = we ? we->dgrad : NULL; mid_conv_dgrad(G.compute, &c->ws, w, d_conv_out, dx, addend, N, C, H, K, k, stride); c->ws.pre_dgrad = NULL; }
+    if (dx) conv_dgrad_t(t, w, d_conv_out, dx, addend, C, H, K, k, stride);
     if (c->overlap_wgrad) {
         mid_event_record(c->ev_bn_done, G.compute);
         mid_stream_wait_event(G.aux, c->ev_bn_done);
-        mid_conv_wgrad(G.aux, &c->ws, in, d_conv_out, dw, N, C, H, K, k, stride);
+        conv_wgrad_t(t, G.aux, in, d_conv_out, dw, C, H, K, k, stride, stem);
         mid_event_record(c->ev_wgrad_done, G.aux);
         c->wgrad_pending = 1;
-    } else mid_conv_wgrad(G.compute, &c->ws, in, d_conv_out, dw, N, C, H, K, k, stride);
+    } else conv_wgrad_t(t, G.compute, in, d_conv_out, dw, C, H, K, k, stride, stem);
 }
 
 /* resnet.cu:1777-2248 */
@@ -629,17 +806,21 @@ void backwards_pass(Train_ResNet *t) {
     const Params *dp = bb->param_derivs;
     Activations *da = bb->activation_derivs;
     const int N = t->batch_size, L = d->output, D = d->final_depth, nb = d->n_conv_blocks;
+    const int recompute = c->policy == MI_STORE_RECOMPUTE_BN;
     mid_event_record(c->ev_t[2], G.compute);
+    if (g_params_dirty) relayout_weights(c); /* parameters were rewritten from the host after forward_pass */
     c->dp_cursor = c->arena_floats;
+    c->n_buckets = 0;
     /* dlogits = softmax - onehot, batch SUM (no 1/N: resnet.cu:1806-1811) */
-    mid_ce_deriv(G.compute, t->forward_buffer->pred, t->cur_batch->correct_classes, bb->output_layer_deriv, N, L);
+    ck(mid_ce_deriv(G.compute, t->forward_buffer->pred, t->cur_batch->correct_classes, bb->output_layer_deriv, N, L), "cross-entropy derivative");
     /* FC: dW = pooled^T dlogits (:1823), dpooled = dlogits W^T (:1830) -- no transposed temporaries */
-    mid_gemm_tn(G.compute, a->final_conv_output_pooled, bb->output_layer_deriv, dp->fully_connected, D, N, L);
-    mid_gemm_nt(G.compute, bb->output_layer_deriv, p->fully_connected, da->final_conv_output_pooled, N, L, D);
+    ck(mid_gemm_tn(G.compute, a->final_conv_output_pooled, bb->output_layer_deriv, dp->fully_connected, D, N, L), "FC wgrad");
+    ck(mid_gemm_nt(G.compute, bb->output_layer_deriv, p->fully_connected, da->final_conv_output_pooled, N, L, D), "FC dgrad");
     mi_dp_reduce_ready(t, (size_t)(dp->fully_connected - c->g_arena), 0);
     const ConvBlock *last = p->conv_blocks[nb - 1];
     const int Hl = last->incoming_spatial_dim;
-    mid_avgpool_bwd(G.compute, da->final_conv_output_pooled, da->activation_conv_blocks[nb - 1]->output_activated, N, D, Hl * Hl);
+    ck(mid_avgpool_bwd_t(G.compute, da->final_conv_output_pooled, da->activation_conv_blocks[nb - 1]->output_activated, c->dtype, N, D, Hl * Hl),
+       "average pool backward");
     const int ring = c->overlap_wgrad == 2;
     for (int i = nb - 1; i >= 0; i--) {
         const ConvBlock *b = p->conv_blocks[i];
@@ -661,7 +842,7 @@ void backwards_pass(Train_ResNet *t) {
              * pass also leaves relu'(out) * up in dk->output, which the expansion BN' then reads instead of up + mask */
             unit_bwd(t, bin, b->projection, b->norm_projection, k->norm_post_projection, db->norm_projection,
                      k->transformed_residual, up, k->output_activated, 3, dk->output, dk->transformed_residual, s_proj, dbin, NULL,
-                     db->projection, b->incoming_filters, H, b->expanded_depth, b->stride == 2 ? 3 : 1, b->stride);
+                     db->projection, b->incoming_filters, H, b->expanded_depth, b->stride == 2 ? 3 : 1, b->stride, 0);
             exp_dy = dk->output; exp_mask = NULL; exp_mode = 0;
             red_addend = dbin; /* reduce-conv dgrad accumulates onto the projection path (toAdd, :2157) */
         } else {
@@ -671,30 +852,73 @@ void backwards_pass(Train_ResNet *t) {
             red_addend = dk->output; /* identity shortcut: setVal 0 + addVec (:2003-2004) folded into the dgrad epilogue */
         }
         if (ring) { dk->post_expanded = ring_take(c, &s_exp); dk->post_spatial_activated = ring_take(c, NULL); }
+        if (recompute) /* the expansion's input, re-derived: relu(BN(post_spatial)) (resnet_clean.cu:2753) */
+            ck(mid_bn_apply_t(G.compute, k->post_spatial, c->dtype, b->norm_spatial->gamma, b->norm_spatial->beta, NULL, k->norm_post_spatial->means,
+                              k->norm_post_spatial->vars, k->post_spatial_activated, c->dtype, N, b->reduced_depth, Ho * Ho, t->eps, 1), "BN recompute");
         unit_bwd(t, k->post_spatial_activated, b->depth_expansion, b->norm_expansion, k->norm_post_expanded,
                  db->norm_expansion, k->post_expanded, exp_dy, exp_mask, exp_mode, dk->output, dk->post_expanded, s_exp,
-                 dk->post_spatial_activated, NULL, db->depth_expansion, b->reduced_depth, Ho, b->expanded_depth, 1, 1);
+                 dk->post_spatial_activated, NULL, db->depth_expansion, b->reduced_depth, Ho, b->expanded_depth, 1, 1, 0);
         /* the call resnet.cu:2060-2083 forgot; present in resnet_cudnn.cu:2365-2366 */
         if (ring) { dk->post_spatial = ring_take(c, &s_spa); dk->post_reduced_activated = ring_take(c, NULL); }
+        if (recompute) /* the 3x3's input, re-derived: relu(BN(post_reduced)) (resnet_clean.cu:2714) */
+            ck(mid_bn_apply_t(G.compute, k->post_reduced, c->dtype, b->norm_depth_reduction->gamma, b->norm_depth_reduction->beta, NULL,
+                              k->norm_post_reduced->means, k->norm_post_reduced->vars, k->post_reduced_activated, c->dtype, N, b->reduced_depth,
+                              H * H, t->eps, 1), "BN recompute");
         unit_bwd(t, k->post_reduced_activated, b->spatial, b->norm_spatial, k->norm_post_spatial, db->norm_spatial,
                  k->post_spatial, dk->post_spatial_activated, NULL, 1, NULL, dk->post_spatial, s_spa, dk->post_reduced_activated, NULL,
-                 db->spatial, b->reduced_depth, H, b->reduced_depth, 3, b->stride);
+                 db->spatial, b->reduced_depth, H, b->reduced_depth, 3, b->stride, 0);
         if (ring) dk->post_reduced = ring_take(c, &s_red);
         unit_bwd(t, bin, b->depth_reduction, b->norm_depth_reduction, k->norm_post_reduced, db->norm_depth_reduction,
                  k->post_reduced, dk->post_reduced_activated, NULL, 1, NULL, dk->post_reduced, s_red, dbin, red_addend,
-                 db->depth_reduction, b->incoming_filters, H, b->reduced_depth, 1, 1);
+                 db->depth_reduction, b->incoming_filters, H, b->reduced_depth, 1, 1, 0);
         mi_dp_reduce_ready(t, (size_t)(db->depth_reduction - c->g_arena), 0);
     }
     const int Hs = d->input / d->init_conv_stride;
     int s_stem = -1;
     if (ring) { da->init_conv_activated = ring_take(c, NULL); da->init_conv_applied = ring_take(c, &s_stem); }
-    mid_maxpool_bwd(G.compute, a->max_inds, da->init_convblock_input, da->init_conv_activated, N, d->init_conv_filters, Hs,
-                    d->init_maxpool_dim, d->init_maxpool_stride);
+    ck(mid_maxpool_bwd_t(G.compute, a->max_inds, da->init_convblock_input, da->init_conv_activated, c->dtype, N, d->init_conv_filters, Hs,
+                         d->init_maxpool_dim, d->init_maxpool_stride), "max-pool backward");
     unit_bwd(t, t->cur_batch->images, p->init_conv_layer, p->norm_init_conv, a->norm_init_conv, dp->norm_init_conv,
              a->init_conv_applied, da->init_conv_activated, NULL, 1, NULL, da->init_conv_applied, s_stem, NULL, NULL,
-             dp->init_conv_layer, 3, d->input, d->init_conv_filters, d->init_kernel_dim, d->init_conv_stride);
+             dp->init_conv_layer, 3, d->input, d->init_conv_filters, d->init_kernel_dim, d->init_conv_stride, 1);
     mi_dp_reduce_ready(t, 0, 1);
     mid_event_record(c->ev_t[3], G.compute);
+}
+
+/* Where the data-parallel path may cut the gradient arena: after the FC layer, after each block (walking backwards) and at
+ * the end of backward.  A bucket is emitted at a cut as soon as at least bucket_bytes are pending.  Pure arithmetic on the
+ * arena offsets (the carve order of build_params), shared by backwards_pass and mi_debug_dp_plan. */
+int mi_dp_plan_buckets(const Dims *d, size_t bucket_bytes, size_t *from, size_t *to, int max) {
+    size_t arena;
+    (void)count_locations(d, &arena);
+    /* offsets of each block's first tensor and of the FC tensor */
+    size_t *boff = (size_t *)malloc(sizeof(size_t) * (size_t)(d->n_conv_blocks + 1));
+    int inc = d->init_conv_filters, ex = 4 * inc, red = inc;
+    size_t off = align_up((size_t)d->init_kernel_dim * d->init_kernel_dim * inc * 3) + 2 * align_up(inc);
+    for (int i = 0; i < d->n_conv_blocks; i++) {
+        int stride = 1;
+        if (d->is_block_spatial_reduction[i] == 1) { stride = 2; red *= 2; ex *= 2; }
+        boff[i] = off;
+        off += align_up((size_t)inc * red) + align_up((size_t)red * red * 9) + align_up((size_t)ex * red) + 4 * align_up(red) + 2 * align_up(ex);
+        if (inc != ex) off += align_up((size_t)inc * ex * (stride == 2 ? 9 : 1)) + 2 * align_up(ex);
+        inc = ex;
+    }
+    const size_t fc_off = off;
+    int n = 0;
+    size_t cursor = arena;
+#define CUT(from_, force_)                                                                      \
+    do {                                                                                        \
+        if ((from_) < cursor && ((force_) || (cursor - (from_)) * sizeof(float) >= bucket_bytes)) { \
+            if (n < max) { from[n] = (from_); to[n] = cursor; }                                  \
+            n++; cursor = (from_);                                                              \
+        }                                                                                       \
+    } while (0)
+    CUT(fc_off, 0);
+    for (int i = d->n_conv_blocks - 1; i >= 0; i--) CUT(boff[i], 0);
+    CUT((size_t)0, 1);
+#undef CUT
+    free(boff);
+    return n;
 }
 
 /* data parallel: hand the finished tail [from, cursor) of the gradient arena to RCCL on the comm stream as soon
@@ -708,49 +932,66 @@ void mi_dp_reduce_ready(Train_ResNet *t, size_t from, int force) {
     if (from >= c->dp_cursor) return;
     const size_t n = c->dp_cursor - from;
     if (!force && n * sizeof(float) < c->bucket_bytes) return;
+    if (c->n_buckets >= MI_MAX_BUCKETS) { if (!force) return; from = 0; } /* more cuts than event slots: the rest goes as one */
     mid_event_record(c->ev_grads, G.compute);
     mid_stream_wait_event(G.comm, c->ev_grads);
     /* the bucket also holds weight gradients from the aux stream: the comm stream waits for the latest of them itself,
      * the compute stream does not stall */
     if (pending) mid_stream_wait_event(G.comm, c->ev_wgrad_done);
-    mid_rccl_allreduce_sum(c->comm, c->g_arena + from, n, G.comm);
+    ck(mid_rccl_allreduce_sum(c->comm, c->g_arena + from, c->dp_cursor - from, G.comm), "RCCL all-reduce");
+    const int b = c->n_buckets < MI_MAX_BUCKETS ? c->n_buckets++ : MI_MAX_BUCKETS - 1;
+    c->bk_from[b] = from; c->bk_to[b] = c->dp_cursor;
+    mid_event_record(c->bk_ev[b], G.comm);
     c->dp_cursor = from;
     c->dp_pending = 1;
 }
 
-void dump_trainer(int dump_id, Train_ResNet *trainer, const char *special_dir);
-
-/* resnet.cu:2910-2987 */
+/* resnet.cu:2910-2987.  No host synchronisation in here: the NaN / Inf flag is copied back asynchronously and read at the
+ * next synchronisation point (forward_pass's pred copy), and with a communicator Adam runs bucket by bucket, each launch
+ * waiting only for its own bucket's all-reduce -- the FC ... stage-3 updates run while the stem-side buckets are still on
+ * the wire, and the host is free to queue the next load_new_batch / forward_pass behind them. */
 void update_parameters(Train_ResNet *t) {
     MiCtx *c = ctx_of(t);
     const Params *p = t->model->params;
+    float *p_arena = mi_params_arena_base(p);
     const float cur_b1 = t->cur_mean_decay * t->base_mean_decay; /* decays advance BEFORE use (:2920-2921) */
     const float cur_b2 = t->cur_var_decay * t->base_var_decay;
-    if (c->dump_every > 0 && t->cur_dump_id % c->dump_every == 0) dump_trainer(t->cur_dump_id, t, t->dump_dir);
-    mid_event_record(c->ev_t[4], G.compute);
-    if (c->dp_pending) {
-        mid_event_record(c->ev_reduced, G.comm);
-        mid_stream_wait_event(G.compute, c->ev_reduced);
-        c->dp_pending = 0;
+    if (c->dump_every > 0 && t->cur_dump_id % c->dump_every == 0) {
+        if (c->dp_pending) mid_stream_sync(G.comm); /* the dump reads the gradient arena: not while RCCL is reducing it */
+        dump_trainer(t->cur_dump_id, t, t->dump_dir);
     }
-    mid_adam(G.compute, mi_params_arena_base(p), c->g_arena, c->m_arena, c->v_arena, c->arena_floats, t->learning_rate,
-             t->weight_decay, t->base_mean_decay, t->base_var_decay, cur_b1, cur_b2, t->eps, c->nan_flag_dev);
-    mid_memset(c->g_arena, 0, c->arena_floats * sizeof(float), G.compute); /* :2972-2978 */
+    mid_event_record(c->ev_t[4], G.compute);
+    if (c->dp_pending && c->n_buckets > 0) {
+        for (int b = 0; b < c->n_buckets; b++) {
+            mid_stream_wait_event(G.compute, c->bk_ev[b]);
+            const size_t o = c->bk_from[b], n = c->bk_to[b] - c->bk_from[b];
+            ck(mid_adam(G.compute, p_arena + o, c->g_arena + o, c->m_arena + o, c->v_arena + o, n, t->learning_rate, t->weight_decay,
+                        t->base_mean_decay, t->base_var_decay, cur_b1, cur_b2, t->eps, c->nan_flag_dev, 1), "Adam");
+        }
+        c->dp_pending = 0; c->n_buckets = 0;
+    } else {
+        /* one launch over the whole arena; it also clears the gradients (:2972-2978) */
+        ck(mid_adam(G.compute, p_arena, c->g_arena, c->m_arena, c->v_arena, c->arena_floats, t->learning_rate, t->weight_decay,
+                    t->base_mean_decay, t->base_var_decay, cur_b1, cur_b2, t->eps, c->nan_flag_dev, 1), "Adam");
+    }
     if (c->input_reset) { /* :2981-2982 */
         mid_memset(t->cur_batch->images, 0, (size_t)t->batch_size * t->cur_batch->image_size * sizeof(float), G.compute);
         mid_memset(t->cur_batch->correct_classes, 0, (size_t)t->batch_size * sizeof(int), G.compute);
     }
     mid_event_record(c->ev_t[5], G.compute);
     mid_memcpy_d2h(c->nan_flag_host, c->nan_flag_dev, sizeof(int), G.compute);
-    mid_stream_sync(G.compute);
-    if (*c->nan_flag_host) { /* check_errors, resnet.cu:2879-2907 */
-        printf("ERROR: nan or inf found in parameters, gradients or Adam moments\n");
-        printf("Dumping data to id=99999999 and exiting...\n");
-        dump_trainer(99999999, t, t->dump_dir);
-        exit(1);
-    }
+    c->nan_check_pending = 1;
+    g_params_dirty = 1; /* the re-laid weight copies are stale until the next forward_pass */
     t->cur_mean_decay = cur_b1;
     t->cur_var_decay = cur_b2;
+}
+/* check_errors on demand (resnet.cu:2879-2907): waits for the device and reads the flag of the last update */
+int mi_trainer_check_errors(Train_ResNet *t) {
+    MiCtx *c = ctx_of(t);
+    mid_stream_sync(G.compute);
+    const int bad = c->nan_check_pending && *c->nan_flag_host;
+    poll_nan_flag(t);
+    return bad;
 }
 
 /* ---------------------------------------------------------------------------------------------- */
@@ -772,7 +1013,8 @@ void destroy_trainer(Train_ResNet *t) {
     const Dims *d = t->model->dims;
     if (c->comm) mid_rccl_comm_destroy(c->comm);
     for (int i = 0; i < c->n_allocs; i++) mid_free(c->allocs[i]);
-    free(c->allocs);
+    free(c->allocs); free(c->alloc_bytes);
+    for (int i = 0; i < MI_MAX_BUCKETS; i++) mid_event_destroy(c->bk_ev[i]);
     mid_free_host(t->forward_buffer->pred_cpu);
     mid_free_host(c->nan_flag_host);
     mid_event_destroy(c->ev_grads); mid_event_destroy(c->ev_reduced);
@@ -810,3 +1052,13 @@ int mi_dp_init(Train_ResNet *t, int rank, int world, const void *unique_id, int 
 }
 void mi_dp_set_bucket_bytes(Train_ResNet *t, size_t bytes) { ctx_of(t)->bucket_bytes = bytes; }
 int mi_dp_world(const Train_ResNet *t) { return ((MiCtx *)t->backend_ctx)->world; }
+
+/* host-only view of the bucket plan (no GPU touched): the cuts backwards_pass will make for this network */
+int mi_debug_dp_plan(const Dims *d, size_t bucket_bytes, size_t *from, size_t *to, int max) { return mi_dp_plan_buckets(d, bucket_bytes, from, to, max); }
+size_t mi_debug_arena_floats(const Dims *d) { size_t a; (void)count_locations(d, &a); return a; }
+/* the buckets the last backwards_pass actually handed to RCCL (valid until update_parameters) */
+int mi_debug_last_buckets(const Train_ResNet *t, size_t *from, size_t *to, int max) {
+    const MiCtx *c = (const MiCtx *)t->backend_ctx;
+    for (int i = 0; i < c->n_buckets && i < max; i++) { from[i] = c->bk_from[i]; to[i] = c->bk_to[i]; }
+    return c->n_buckets;
+}

@@ -172,3 +172,108 @@ class Ops:
         dx, do = self.dev(x), self.dev(shape=(N, Cc, H, W))
         self._chk(self.L.mi_op_nhwc_to_nchw(dx.ptr, do.ptr, N, H, W, Cc), "nhwc_to_nchw")
         return do.get()
+
+    # ---- typed operators: activation tensors stored as bf16 on the device, numpy float32 at this boundary ----
+    # (values are rounded to bf16 -- round to nearest even -- on the way in; outputs come back widened, so a bf16 result
+    # is a float32 array whose values are exactly the stored bf16 numbers)
+    def dev_t(self, arr, dt):
+        """upload a float32 array as a tensor of storage type dt"""
+        d32 = self.dev(np.ascontiguousarray(arr, np.float32))
+        if dt == B.MI_DTYPE_F32:
+            return d32
+        out = DeviceArray(self.L, shape=arr.shape, dtype=np.uint16)
+        self._chk(self.L.mi_op_convert(d32.ptr, B.MI_DTYPE_F32, out.ptr, B.MI_DTYPE_BF16, arr.size), "convert")
+        return out
+
+    def new_t(self, shape, dt):
+        return DeviceArray(self.L, shape=shape, dtype=np.float32 if dt == B.MI_DTYPE_F32 else np.uint16)
+
+    def get_t(self, darr, dt):
+        if dt == B.MI_DTYPE_F32:
+            return darr.get()
+        out = self.dev(shape=darr.shape)
+        self._chk(self.L.mi_op_convert(darr.ptr, B.MI_DTYPE_BF16, out.ptr, B.MI_DTYPE_F32, int(np.prod(darr.shape))), "convert")
+        return out.get()
+
+    def conv_fwd_bf16(self, x, w, stride):
+        N, Cc, H, _ = x.shape
+        K, _, k, _ = w.shape
+        BF = B.MI_DTYPE_BF16
+        dx, dw = self.dev_t(x, BF), self.dev(w)
+        dy = self.new_t((N, K, H // stride, H // stride), BF)
+        self._chk(self.L.mi_op_conv_fwd_bf16(dx.ptr, dw.ptr, dy.ptr, N, Cc, H, K, k, stride), "conv_fwd_bf16")
+        return self.get_t(dy, BF)
+
+    def conv_dgrad_bf16(self, w, dy, H, stride, dx_init=None):
+        K, Cc, k, _ = w.shape
+        N = dy.shape[0]
+        BF = B.MI_DTYPE_BF16
+        dw_, ddy = self.dev(w), self.dev_t(dy, BF)
+        ddx = self.dev_t(dx_init, BF) if dx_init is not None else self.new_t((N, Cc, H, H), BF)
+        self._chk(self.L.mi_op_conv_dgrad_bf16(dw_.ptr, ddy.ptr, ddx.ptr, N, Cc, H, K, k, stride, 0 if dx_init is None else 1), "conv_dgrad_bf16")
+        return self.get_t(ddx, BF)
+
+    def conv_wgrad_bf16(self, x, dy, k, stride):
+        N, Cc, H, _ = x.shape
+        K = dy.shape[1]
+        BF = B.MI_DTYPE_BF16
+        dx, ddy = self.dev_t(x, BF), self.dev_t(dy, BF)
+        dw = self.dev(shape=(K, Cc, k, k))
+        self._chk(self.L.mi_op_conv_wgrad_bf16(dx.ptr, ddy.ptr, dw.ptr, N, Cc, H, K, k, stride), "conv_wgrad_bf16")
+        return dw.get()
+
+    def bn_fwd_t(self, x, gamma, beta, eps, relu, x_dt, a_dt, residual=None):
+        N, Cc, H, _ = x.shape
+        dx, dg, db = self.dev_t(x, x_dt), self.dev(gamma), self.dev(beta)
+        dm, dv, dy = self.dev(shape=(Cc,)), self.dev(shape=(Cc,)), self.new_t(x.shape, a_dt)
+        dr = self.dev_t(residual, a_dt) if residual is not None else None
+        self._chk(self.L.mi_op_bn_fwd_t(dx.ptr, x_dt, dg.ptr, db.ptr, dr.ptr if dr else None, dm.ptr, dv.ptr, dy.ptr, a_dt, N, Cc, H, eps,
+                                        int(relu)), "bn_fwd_t")
+        return dm.get(), dv.get(), self.get_t(dy, a_dt)
+
+    def bn_apply_t(self, x, gamma, beta, means, vars_, eps, relu, x_dt, a_dt, residual=None):
+        N, Cc, H, _ = x.shape
+        dx, dg, db, dm, dv = self.dev_t(x, x_dt), self.dev(gamma), self.dev(beta), self.dev(means), self.dev(vars_)
+        dy = self.new_t(x.shape, a_dt)
+        dr = self.dev_t(residual, a_dt) if residual is not None else None
+        self._chk(self.L.mi_op_bn_apply_t(dx.ptr, x_dt, dg.ptr, db.ptr, dr.ptr if dr else None, dm.ptr, dv.ptr, dy.ptr, a_dt, N, Cc, H, eps,
+                                          int(relu)), "bn_apply_t")
+        return self.get_t(dy, a_dt)
+
+    def bn_bwd_t(self, x, gamma, beta, means, vars_, dy, eps, mask_mode, x_dt, a_dt, mask_src=None):
+        """returns dx, dgamma, dbeta (and the gated dy for mask_mode 3)"""
+        N, Cc, H, _ = x.shape
+        dx, ddy = self.dev_t(x, x_dt), self.dev_t(dy, a_dt)
+        dg, db, dm, dv = (self.dev(a) for a in (gamma, beta, means, vars_))
+        dmask = self.dev_t(mask_src, a_dt) if mask_src is not None else None
+        gated = self.new_t(x.shape, a_dt) if mask_mode == 3 else None
+        out, ogam, obet = self.new_t(x.shape, x_dt), self.dev(shape=(Cc,)), self.dev(shape=(Cc,))
+        self._chk(self.L.mi_op_bn_bwd_t(dx.ptr, x_dt, dg.ptr, db.ptr, dm.ptr, dv.ptr, ddy.ptr, dmask.ptr if dmask else None,
+                                        gated.ptr if gated else None, a_dt, out.ptr, ogam.ptr, obet.ptr, N, Cc, H, eps, mask_mode), "bn_bwd_t")
+        res = (self.get_t(out, x_dt), ogam.get(), obet.get())
+        return res + (self.get_t(gated, a_dt),) if gated else res
+
+    def maxpool_fwd_t(self, x, k, stride, dt):
+        N, Cc, H, _ = x.shape
+        Ho = H // stride
+        dx, dy, di = self.dev_t(x, dt), self.new_t((N, Cc, Ho, Ho), dt), self.dev(shape=(N, Cc, Ho, Ho), dtype=np.int32)
+        self._chk(self.L.mi_op_maxpool_fwd_t(dx.ptr, dy.ptr, dt, di.ptr, N, Cc, H, k, stride), "maxpool_fwd_t")
+        return self.get_t(dy, dt), di.get()
+
+    def maxpool_bwd_t(self, idx, dy, H, k, stride, dt):
+        N, Cc = dy.shape[:2]
+        di, ddy, dx = self.dev(idx.astype(np.int32)), self.dev_t(dy, dt), self.new_t((N, Cc, H, H), dt)
+        self._chk(self.L.mi_op_maxpool_bwd_t(di.ptr, ddy.ptr, dx.ptr, dt, N, Cc, H, k, stride), "maxpool_bwd_t")
+        return self.get_t(dx, dt)
+
+    def avgpool_fwd_t(self, x, dt):
+        N, Cc, H, _ = x.shape
+        dx, dy = self.dev_t(x, dt), self.dev(shape=(N, Cc))
+        self._chk(self.L.mi_op_avgpool_fwd_t(dx.ptr, dt, dy.ptr, N, Cc, H), "avgpool_fwd_t")
+        return dy.get()
+
+    def avgpool_bwd_t(self, dy, H, dt):
+        N, Cc = dy.shape
+        ddy, dx = self.dev(dy), self.new_t((N, Cc, H, H), dt)
+        self._chk(self.L.mi_op_avgpool_bwd_t(ddy.ptr, dx.ptr, dt, N, Cc, H), "avgpool_bwd_t")
+        return self.get_t(dx, dt)

@@ -42,6 +42,31 @@ class Trainer:
         self.n_locations = p.n_locations
         self.sizes = [p.sizes[i] for i in range(p.n_locations)]
         L.mi_trainer_set_dump_every(self.t, 0)
+        self.dtype = B.MI_DTYPE_F32
+
+    # ---- options (before the first step) ----
+    def set_dtype(self, dtype):
+        """MI_DTYPE_BF16: activations / activation gradients stored as bf16 (BASELINE configs[4])"""
+        if self.L.mi_trainer_set_dtype(self.t, int(dtype)) != 0:
+            e = self.error()
+            self.L.mi_clear_error()
+            raise RuntimeError("mi_trainer_set_dtype: " + e)
+        self.dtype = int(dtype)
+
+    def set_store_policy(self, policy):
+        if self.L.mi_trainer_set_store_policy(self.t, int(policy)) != 0:
+            e = self.error()
+            self.L.mi_clear_error()
+            raise RuntimeError("mi_trainer_set_store_policy: " + e)
+
+    def activation_bytes(self):
+        return int(self.L.mi_trainer_activation_bytes(self.t))
+
+    def device_bytes(self):
+        return int(self.L.mi_trainer_device_bytes(self.t))
+
+    def check_errors(self):
+        return int(self.L.mi_trainer_check_errors(self.t))
 
     # ---- plumbing ----
     def error(self):
@@ -61,6 +86,14 @@ class Trainer:
         out = np.empty(n, dtype)
         self.L.mi_copy_to_host(out.ctypes.data, C.cast(ptr, C.c_void_p), n * 4)
         return out
+
+    def _act_to_host(self, ptr, n):
+        """an activation-typed tensor (bf16 in bf16 mode) widened to float32"""
+        if self.dtype == B.MI_DTYPE_F32:
+            return self._to_host(ptr, n)
+        raw = np.empty(n, np.uint16)
+        self.L.mi_copy_to_host(raw.ctypes.data, C.cast(ptr, C.c_void_p), n * 2)
+        return (raw.astype(np.uint32) << 16).view(np.float32)
 
     def _to_dev(self, ptr, arr):
         arr = np.ascontiguousarray(arr)
@@ -157,10 +190,12 @@ class Trainer:
         Hp = Hs // d["init_maxpool_stride"]
         if name == "input":
             return self._to_host(self.c_batch.contents.images, N * 3 * d["input"] ** 2).reshape(N, 3, d["input"], d["input"])
-        if name in ("init_conv_applied", "init_conv_activated"):
-            return self._to_host(getattr(a, name), N * f * Hs * Hs).reshape(N, f, Hs, Hs)
+        if name == "init_conv_applied":  # the stem convolution's tensors are fp32 in every storage type
+            return self._to_host(a.init_conv_applied, N * f * Hs * Hs).reshape(N, f, Hs, Hs)
+        if name == "init_conv_activated":
+            return self._act_to_host(a.init_conv_activated, N * f * Hs * Hs).reshape(N, f, Hs, Hs)
         if name == "init_convblock_input":
-            return self._to_host(a.init_convblock_input, N * f * Hp * Hp).reshape(N, f, Hp, Hp)
+            return self._act_to_host(a.init_convblock_input, N * f * Hp * Hp).reshape(N, f, Hp, Hp)
         if name == "max_inds":
             return self._to_host(a.max_inds, N * f * Hp * Hp, np.int32).reshape(N, f, Hp, Hp)
         if name == "final_avg_pool":
@@ -185,7 +220,7 @@ class Trainer:
             ptr = getattr(k, field)
             if not ptr:
                 raise KeyError(name + " is not stored (fast path); enable full-store")
-            return self._to_host(ptr, N * ch * hh * hh).reshape(N, ch, hh, hh)
+            return self._act_to_host(ptr, N * ch * hh * hh).reshape(N, ch, hh, hh)
         if name.startswith("batch_norms/"):
             parts = name.split("/")
             if parts[1] == "init":

@@ -101,3 +101,68 @@ class TorchNet:
     def backward(self):
         self.loss.backward()
         return [p.grad.detach().numpy() for p in self.p]
+
+
+# ---- bf16-storage emulation (BASELINE configs[4]): the same float64 model with every ACTIVATION tensor and every activation
+# gradient rounded to bf16 (round to nearest even) where the product stores it: convolution outputs of the bottleneck
+# blocks, BN(+ReLU) outputs, block outputs, and the gradients flowing back through the same tensors; bottleneck weights
+# are rounded when used (fp32 master copies).  The stem convolution's own output stays unrounded, like the product's.
+# It is the yardstick for how far bf16 storage ALONE moves a gradient from the fp32 oracle's (tests/test_gpu_bf16.py): on
+# these small random-init nets a rounded pre-activation flips ~0.3 % of the ReLU gates per layer, which is ~5 % in rel-L2.
+def _rb(t):
+    return t.to(torch.float32).to(torch.bfloat16).to(t.dtype)
+
+
+class _RoundBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return _rb(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _rb(g)
+
+
+class TorchNetBF16(TorchNet):
+    def _unit(self, x, i, K, C, k, stride, relu, name, residual=None):
+        w = self.p[i].view(K, C, k, k)
+        stem = name == "stem"
+        if not stem:
+            w = w + (_rb(w.detach()) - w.detach())  # rounded value, gradient to the fp32 master copy
+        y = F.conv2d(x, w, stride=stride, padding=k // 2)
+        if not stem:
+            y = _RoundBF16.apply(y)
+        z = bn_train(y, self.p[i + 1], self.p[i + 2], self.eps)
+        if residual is not None:
+            z = F.relu(z + residual)  # BN + addVec + doActivation are one kernel: one rounding
+        elif relu:
+            z = F.relu(z)
+        return _RoundBF16.apply(z)
+
+    def forward(self, images_nchw, labels):
+        d = self.dims
+        x = torch.tensor(images_nchw, dtype=self.p[0].dtype)
+        f = d["init_conv_filters"]
+        li = 0
+        x = self._unit(x, li, f, 3, d["init_kernel_dim"], d["init_conv_stride"], True, "stem")
+        li += 3
+        x = MaxPoolOverwrite.apply(x, d["init_maxpool_dim"], d["init_maxpool_stride"])
+        inc, red, ex = f, f, 4 * f
+        for b in range(d["n_conv_blocks"]):
+            stride = 1
+            if d["is_block_spatial_reduction"][b]:
+                stride, red, ex = 2, red * 2, ex * 2
+            r = self._unit(x, li, red, inc, 1, 1, True, "red"); li += 3
+            s = self._unit(r, li, red, red, 3, stride, True, "spa"); li += 3
+            le = li; li += 3
+            res = x
+            if inc != ex:
+                res = self._unit(x, li, ex, inc, 3 if stride == 2 else 1, stride, False, "proj"); li += 3
+            x = self._unit(s, le, ex, red, 1, 1, False, "exp", residual=res)
+            inc = ex
+        pooled = x.mean(dim=(2, 3))
+        logits = pooled @ self.p[li].view(inc, d["output"])
+        self.pred = torch.softmax(logits, dim=1)
+        lab = torch.tensor(np.asarray(labels), dtype=torch.long)
+        self.loss = -torch.log(self.pred[torch.arange(len(lab)), lab]).sum()
+        return self.loss
