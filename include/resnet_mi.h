@@ -352,6 +352,16 @@ int mi_debug_dp_plan(const Dims *d, size_t bucket_bytes, size_t *from, size_t *t
 size_t mi_debug_arena_floats(const Dims *d);
 int mi_debug_last_buckets(const Train_ResNet *t, size_t *from, size_t *to, int max);
 
+/* the offline shard writer, build_training_shards.c:13-167 with its literal paths as arguments: reads the partition CSV
+ * ("CCC,NNNN,RR,CC" per line) and <class_dir>/%08d.buffer (uint8, dim_in x dim_in x 3, B,G,R), crops dim_out x dim_out at the
+ * per-image offsets, converts to R,G,B floats minus 103.94 / 116.78 / 123.68, writes <out_dir>/%03d.images (fp32, NCHW like the
+ * reference, or NHWC) and %03d.labels (int32).  Returns the number of images written, < 0 on error. */
+int mi_build_shard(const char *partition_csv, const char *class_dir, const char *out_dir, int shard_id, int image_dim_in,
+                   int image_dim_out, int layout);
+/* data parallel: this rank's slice of every global batch of a shard ("each rank reads its slice of the same
+ * shard/batch"): global batch g of a shard = images [g*world*N, (g+1)*world*N), rank r takes [.. + r*N, .. + (r+1)*N) */
+void mi_batch_set_rank_slice(Batch *b, int rank, int world);
+
 /* typed operator layer: x_dt = storage type of the convolution-side tensors (x, dx), a_dt = of the activation-side tensors
  * (y, residual, dy, mask_src, gated_out).  Supported pairs: (F32,F32), (BF16,BF16), (F32,BF16). */
 int mi_op_convert(const void *in, int in_dt, void *out, int out_dt, size_t n);

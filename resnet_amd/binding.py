@@ -181,6 +181,8 @@ PROTOTYPES = {
     "mi_debug_dp_plan": (_i, [C.POINTER(Dims), _sz, _vp, _vp, _i]),
     "mi_debug_arena_floats": (_sz, [C.POINTER(Dims)]),
     "mi_debug_last_buckets": (_i, [_T, _vp, _vp, _i]),
+    "mi_build_shard": (_i, [_cp, _cp, _cp, _i, _i, _i, _i]),
+    "mi_batch_set_rank_slice": (None, [_B, _i, _i]),
     "mi_op_convert": (_i, [_vp, _i, _vp, _i, _sz]),
     "mi_bf16_conv_supported": (_i, [_i] * 7),
     "mi_op_conv_fwd_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),

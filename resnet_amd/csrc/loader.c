@@ -16,7 +16,7 @@ static BatchExt *g_ext = NULL;
 BatchExt *mi_batch_ext(Batch *b) {
     for (BatchExt *e = g_ext; e; e = e->next) if (e->batch == b) return e;
     BatchExt *e = (BatchExt *)calloc(1, sizeof(BatchExt));
-    e->batch = b; e->source = MI_SRC_SHARDS; e->layout = MI_LAYOUT_NCHW;
+    e->batch = b; e->source = MI_SRC_SHARDS; e->layout = MI_LAYOUT_NCHW; e->world = 1;
     e->shard_dir = strdup("/mnt/storage/data/vision/imagenet/2012/train_data_shards"); /* resnet.cu:1275 */
     e->next = g_ext; g_ext = e;
     return e;
@@ -99,6 +99,14 @@ void mi_batch_source_host(Batch *b, int layout) {
     BatchExt *e = mi_batch_ext(b);
     e->source = MI_SRC_HOST; e->layout = layout;
 }
+/* data parallel: global batch g of a shard = images [g*world*N, (g+1)*world*N); rank r reads the r-th N of it.  Every rank
+ * advances cur_batch_in_shard by one per step and rolls to the next shard at the same step. */
+void mi_batch_set_rank_slice(Batch *b, int rank, int world) {
+    BatchExt *e = mi_batch_ext(b);
+    if (world < 1) world = 1;
+    if (rank < 0 || rank >= world) rank = 0;
+    e->rank = rank; e->world = world; e->have_next = 0;
+}
 int mi_batch_last_status(const Batch *b) { return mi_batch_ext((Batch *)b)->status; }
 
 /* Synthetic pool: batch j of the pool = stream elements [j*n, (j+1)*n) of the two seeds, generated on the
@@ -153,9 +161,9 @@ void load_new_batch(Train_ResNet *trainer, Class_Metadata *class_metadata, Batch
     const size_t total_pixels = (size_t)N * b->image_size;
     e->status = 0;
     if (e->source == MI_SRC_SHARDS) {
-        int start_img = b->cur_batch_in_shard * N;
+        const int W = e->world, R = e->rank;
         /* later variants skip a ragged tail instead of assuming divisibility (resnet_cudnn_lowmem.cu:1293-1297) */
-        if (trainer->init_loaded || b->cur_shard_id == -1 || start_img + N > b->shard_n_images) {
+        if (trainer->init_loaded || b->cur_shard_id == -1 || (b->cur_batch_in_shard + 1) * W * N > b->shard_n_images) {
             if (!trainer->init_loaded) b->cur_shard_id += 1;
             if (!b->full_shard_images) {
                 b->full_shard_images = (float *)malloc((size_t)b->shard_n_images * b->image_size * sizeof(float));
@@ -174,7 +182,8 @@ void load_new_batch(Train_ResNet *trainer, Class_Metadata *class_metadata, Batch
             trainer->init_loaded = 0;
         }
         if (e->status == 0) {
-            if (e->prefetch && e->have_next && e->next_shard_id == b->cur_shard_id && e->next_batch_in_shard == b->cur_batch_in_shard) {
+            const int bi = b->cur_batch_in_shard * W + R; /* this rank's batch of the shard */
+            if (e->prefetch && e->have_next && e->next_shard_id == b->cur_shard_id && e->next_batch_in_shard == bi) {
                 /* batch already on the device: order the compute stream after the copy and swap buffers */
                 mid_stream_wait_event(g->compute, e->ev_next);
                 mid_event_sync(e->ev_next); /* the pinned staging buffer is rewritten below */
@@ -183,14 +192,14 @@ void load_new_batch(Train_ResNet *trainer, Class_Metadata *class_metadata, Batch
                 memcpy(b->correct_classes_cpu, e->labels_next_host, (size_t)N * sizeof(int));
                 e->have_next = 0;
             } else {
-                memcpy(b->images_float_cpu, b->full_shard_images + (size_t)b->cur_batch_in_shard * total_pixels, total_pixels * sizeof(float));
-                memcpy(b->correct_classes_cpu, b->full_shard_correct_classes + (size_t)b->cur_batch_in_shard * N, (size_t)N * sizeof(int));
+                memcpy(b->images_float_cpu, b->full_shard_images + (size_t)bi * total_pixels, total_pixels * sizeof(float));
+                memcpy(b->correct_classes_cpu, b->full_shard_correct_classes + (size_t)bi * N, (size_t)N * sizeof(int));
                 upload(b, e);
             }
-            if (e->prefetch && (b->cur_batch_in_shard + 2) * N <= b->shard_n_images) {
+            if (e->prefetch && (b->cur_batch_in_shard + 2) * W * N <= b->shard_n_images) {
                 /* the swapped-out buffer may still be read by the step that just ended: that step was synchronised by
                  * update_parameters / forward_pass before the caller got here, so the copy stream can reuse it */
-                prefetch_enqueue(b, e, b->cur_batch_in_shard + 1);
+                prefetch_enqueue(b, e, (b->cur_batch_in_shard + 1) * W + R);
             }
         }
     } else if (e->source == MI_SRC_BUFFER) {

@@ -24,6 +24,7 @@ MiGlobal *mi_global(void);
 typedef struct BatchExt {
     Batch *batch;
     int source, layout, status;
+    int rank, world; /* data parallel: this rank's slice of every global batch of a shard */
     char *shard_dir, *images_path, *labels_path;
     uint64_t seed_images, seed_labels;
     int n_classes, pool_batches, pool_next;
