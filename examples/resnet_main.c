@@ -24,7 +24,8 @@ int main(int argc, char **argv) {
     const int INPUT_DIM = atoi(opt(argc, argv, "--input", "224"));
     const int N_CONV_BLOCKS = atoi(opt(argc, argv, "--blocks", "16"));
     const int BATCH_SIZE = atoi(opt(argc, argv, "--batch", "32"));          /* resnet.cu:3279 */
-    const int iters = atoi(opt(argc, argv, "--iters", "10"));
+    const int iters = atoi(opt(argc, argv, "--iters", "10"));                /* iterations per epoch (reference: ceil(total_images / BATCH_SIZE), :3308) */
+    const int N_EPOCHS = atoi(opt(argc, argv, "--epochs", "1"));              /* resnet.cu:3293 (40) */
     const float LEARNING_RATE = (float)atof(opt(argc, argv, "--lr", "0.0001")); /* resnet.cu:3286-3291 */
     const float WEIGHT_DECAY = (float)atof(opt(argc, argv, "--wd", "0"));
     const float EPS = (float)atof(opt(argc, argv, "--eps", "0.0000001"));
@@ -46,31 +47,45 @@ int main(int argc, char **argv) {
     if (shards) mi_batch_source_shards(batch, shards, !strcmp(layout, "nhwc") ? MI_LAYOUT_NHWC : MI_LAYOUT_NCHW);
     else mi_batch_source_synthetic(batch, 1234, 1235, N_CLASSES, 4);
     if (shards) mi_batch_set_prefetch(batch, 1);
-    Train_ResNet *trainer = init_trainer(model, batch, BATCH_SIZE, LEARNING_RATE, WEIGHT_DECAY, 0.9f, 0.999f, EPS, 40, "my_custom");
+    Train_ResNet *trainer = init_trainer(model, batch, BATCH_SIZE, LEARNING_RATE, WEIGHT_DECAY, 0.9f, 0.999f, EPS, N_EPOCHS, "my_custom");
     if (dump_root) mi_trainer_set_dump_root(trainer, dump_root); else mi_trainer_set_dump_every(trainer, 0);
     if (resume_id != -1) { overwrite_trainer_hyperparams(trainer, resume_id, "my_custom"); overwrite_model_params(trainer, resume_id, "my_custom"); }
 
     FILE *loss_file = fopen(loss_log, "w");
-    for (int iter = 0; iter < iters; iter++) {
-        load_new_batch(trainer, NULL, trainer->cur_batch);
-        if (mi_batch_last_status(trainer->cur_batch)) { fprintf(stderr, "data source exhausted\n"); break; }
-        forward_pass(trainer);
-        const float *pred = trainer->forward_buffer->pred_cpu;
-        const int *correct = trainer->cur_batch->correct_classes_cpu;
-        float batch_loss = 0, batch_n_wrong = 0;
-        for (int s = 0; s < BATCH_SIZE; s++) batch_loss += -1 * logf(pred[s * N_CLASSES + correct[s]]);
-        for (int s = 0; s < BATCH_SIZE; s++) {
-            const float v = pred[s * N_CLASSES + correct[s]];
-            for (int c = 0; c < N_CLASSES; c++)
-                if (c != correct[s] && pred[s * N_CLASSES + c] >= v) { batch_n_wrong++; break; }
+    /* the epoch loop of resnet.cu:3327-3421, including the restart position after a resume (:3324-3325) */
+    const int iterations_per_epoch = iters;
+    const float total_images_per_epoch = (float)BATCH_SIZE * iterations_per_epoch;
+    int cur_iter_in_epoch = (trainer->cur_dump_id + 1) % iterations_per_epoch;
+    int stop = 0;
+    for (int epoch = trainer->cur_epoch; epoch < N_EPOCHS && !stop; epoch++) {
+        float epoch_loss = 0, epoch_n_wrong = 0;
+        for (int iter = cur_iter_in_epoch; iter < iterations_per_epoch; iter++) {
+            load_new_batch(trainer, NULL, trainer->cur_batch);
+            if (mi_batch_last_status(trainer->cur_batch)) { fprintf(stderr, "data source exhausted\n"); stop = 1; break; }
+            forward_pass(trainer);
+            const float *pred = trainer->forward_buffer->pred_cpu;
+            const int *correct = trainer->cur_batch->correct_classes_cpu;
+            float batch_loss = 0, batch_n_wrong = 0;
+            for (int s = 0; s < BATCH_SIZE; s++) batch_loss += -1 * logf(pred[s * N_CLASSES + correct[s]]);
+            for (int s = 0; s < BATCH_SIZE; s++) {
+                const float v = pred[s * N_CLASSES + correct[s]];
+                for (int c = 0; c < N_CLASSES; c++)
+                    if (c != correct[s] && pred[s * N_CLASSES + c] >= v) { batch_n_wrong++; break; }
+            }
+            epoch_loss += batch_loss; epoch_n_wrong += batch_n_wrong;
+            const float avg = batch_loss / BATCH_SIZE, acc = 100 * ((float)BATCH_SIZE - batch_n_wrong) / (float)BATCH_SIZE;
+            printf("\nEpoch: %d, Batch: %d ----- Avg. Loss: %.4f, Accuracy: %.2f%%\n\n", epoch, iter, avg, acc);
+            if (loss_file) { fprintf(loss_file, "%.4f\n", avg); fflush(loss_file); }
+            backwards_pass(trainer);
+            update_parameters(trainer);
+            if (mi_last_error()[0]) { fprintf(stderr, "device error: %s\n", mi_last_error()); return 2; }
         }
-        const float avg = batch_loss / BATCH_SIZE, acc = 100 * ((float)BATCH_SIZE - batch_n_wrong) / (float)BATCH_SIZE;
-        printf("\nEpoch: %d, Batch: %d ----- Avg. Loss: %.4f, Accuracy: %.2f%%\n\n", 0, iter, avg, acc);
-        if (loss_file) { fprintf(loss_file, "%.4f\n", avg); fflush(loss_file); }
-        backwards_pass(trainer);
-        update_parameters(trainer);
-        if (mi_last_error()[0]) { fprintf(stderr, "device error: %s\n", mi_last_error()); return 2; }
+        if (stop) break;
+        /* resnet.cu:3410-3421: per-epoch loss (a SUM over the epoch) and accuracy, rewind the data source */
+        mi_trainer_end_epoch(trainer, epoch_loss, epoch_n_wrong, total_images_per_epoch);
+        cur_iter_in_epoch = 0;
     }
+    mi_trainer_check_errors(trainer);
     if (dump_root) dump_trainer(77777777, trainer, trainer->dump_dir);          /* :3424-3425 */
     if (loss_file) fclose(loss_file);
     destroy_trainer(trainer);

@@ -346,6 +346,8 @@ void mi_clear_error(void);
  * launch; it is read at the next forward_pass, or here (waits for the device; dumps id 99999999 and exits like the reference
  * when set).  Returns 0 when clean. */
 int mi_trainer_check_errors(Train_ResNet *t);
+/* the end-of-epoch bookkeeping of the reference's main() (resnet.cu:3410-3421) */
+void mi_trainer_end_epoch(Train_ResNet *t, float epoch_loss, float epoch_n_wrong, float total_images_per_epoch);
 /* host-only (no GPU needed): the gradient buckets the data-parallel path cuts for a network -- float offsets [from, to) into
  * the gradient arena in issue order (FC side first).  mi_debug_last_buckets: what the last backwards_pass really issued. */
 int mi_debug_dp_plan(const Dims *d, size_t bucket_bytes, size_t *from, size_t *to, int max);

@@ -178,6 +178,7 @@ PROTOTYPES = {
     "mi_trainer_device_bytes": (_sz, [_T]),
     "mi_clear_error": (None, []),
     "mi_trainer_check_errors": (_i, [_T]),
+    "mi_trainer_end_epoch": (None, [_T, _f, _f, _f]),
     "mi_debug_dp_plan": (_i, [C.POINTER(Dims), _sz, _vp, _vp, _i]),
     "mi_debug_arena_floats": (_sz, [C.POINTER(Dims)]),
     "mi_debug_last_buckets": (_i, [_T, _vp, _vp, _i]),

@@ -7,7 +7,9 @@
  * interchangeable with dumps of the reference.  Unlike the reference, directories are created here
  * (it needs build_dirs_for_dumping.ipynb) and a dump that cannot be written is reported and skipped
  * instead of dereferencing a NULL FILE*.  Tensors that the fast path does not keep are skipped
- * (x-hat, BN-out, pre-ReLU sums: call mi_trainer_set_full_store).
+ * (x-hat, BN-out, pre-ReLU sums: MI_STORE_FULL), and so is the image-shaped part of activation_derivs/ unless the policy
+ * is MI_STORE_FULL: outside it the derivative tensors share a few rolling buffers (resnet_cudnn_lowmem.cu:2152-2170) and
+ * would not hold what their file names say.  bf16 tensors are widened to fp32 on the way out: the files are fp32 always.
  */
 #define _GNU_SOURCE
 #include <errno.h>
@@ -41,11 +43,19 @@ static int write_dev(const char *dir, const char *name, const void *dev, size_t 
     free(host); free(path);
     return rc;
 }
-/* NCHW device tensor -> NHWC file */
-static int write_img(const char *dir, const char *name, const float *dev, int N, int C, int H, float *scratch) {
+/* NCHW device tensor (fp32, or bf16 when dt says so) -> NHWC fp32 file */
+static float *g_widen = NULL; /* second scratch of the current dump: bf16 -> fp32 before the transposition */
+static int write_img_t(const char *dir, const char *name, const float *dev, int N, int C, int H, float *scratch, int dt) {
     if (!dev) return 0;
+    if (dt == MID_BF16) {
+        mid_bf16_to_f32(mi_global()->compute, dev, g_widen, (size_t)N * C * H * H);
+        dev = g_widen;
+    }
     mid_nchw_to_nhwc(mi_global()->compute, dev, scratch, N, C, H, H);
     return write_dev(dir, name, scratch, (size_t)N * C * H * H);
+}
+static int write_img(const char *dir, const char *name, const float *dev, int N, int C, int H, float *scratch) {
+    return write_img_t(dir, name, dev, N, C, H, scratch, MID_F32);
 }
 
 /* resnet.cu:2250-2317 */
@@ -78,7 +88,12 @@ static void dump_activations(int dump_id, Train_ResNet *t, Activations *a, int i
     if (asprintf(&base, "%s/%s/%08d/%s", root_of(t), special_dir, dump_id, is_deriv ? "activation_derivs" : "activations") < 0) return;
     size_t maxe = (size_t)N * f * Hs * Hs;
     if ((size_t)N * t->cur_batch->image_size > maxe) maxe = (size_t)N * t->cur_batch->image_size;
+    const MiCtx *ctx = (const MiCtx *)t->backend_ctx;
+    const int adt = ctx->dtype;                                   /* storage type of activation tensors */
+    const int imgs = !is_deriv || ctx->policy == MI_STORE_FULL;    /* see the header: aliased derivative tensors are not written */
+    const int rc = !is_deriv && ctx->policy == MI_STORE_RECOMPUTE_BN; /* the BN(+ReLU) tensors are shared scratch then */
     float *scratch = (float *)mid_malloc(maxe * sizeof(float));
+    g_widen = adt == MID_BF16 ? (float *)mid_malloc(maxe * sizeof(float)) : NULL;
     if (!is_deriv) {
         write_img(base, "input.buffer", t->cur_batch->images, N, 3, d->input, scratch);
         write_dev(base, "max_inds.buffer", a->max_inds, (size_t)N * f * Hp * Hp);
@@ -87,23 +102,27 @@ static void dump_activations(int dump_id, Train_ResNet *t, Activations *a, int i
     } else {
         write_dev(base, "fc_output.buffer", t->backprop_buffer->output_layer_deriv, (size_t)N * d->output);
     }
-    write_img(base, "init_conv_applied.buffer", a->init_conv_applied, N, f, Hs, scratch);
-    write_img(base, "init_conv_activated.buffer", a->init_conv_activated, N, f, Hs, scratch);
-    write_img(base, "init_convblock_input.buffer", a->init_convblock_input, N, f, Hp, scratch);
+    if (imgs) {
+        write_img(base, "init_conv_applied.buffer", a->init_conv_applied, N, f, Hs, scratch); /* the stem's tensors are fp32 */
+        if (!rc) write_img_t(base, "init_conv_activated.buffer", a->init_conv_activated, N, f, Hs, scratch, adt);
+        write_img_t(base, "init_convblock_input.buffer", a->init_convblock_input, N, f, Hp, scratch, adt);
+    }
     if (asprintf(&dir, "%s/batch_norms/init", base) >= 0) { dump_cache(dir, a->norm_init_conv); free(dir); }
     for (int i = 0; i < a->n_conv_blocks; i++) {
         const Activation_ConvBlock *k = a->activation_conv_blocks[i];
         const int H = k->incoming_spatial_dim, Ho = H / k->stride, R = k->reduced_depth, X = k->expanded_depth;
         if (asprintf(&dir, "%s/conv_blocks/%02d", base, i) < 0) break;
-        write_img(dir, "reduction_applied.buffer", k->post_reduced, N, R, H, scratch);
-        write_img(dir, "reduction_activated.buffer", k->post_reduced_activated, N, R, H, scratch);
-        write_img(dir, "spatial_applied.buffer", k->post_spatial, N, R, Ho, scratch);
-        write_img(dir, "spatial_activated.buffer", k->post_spatial_activated, N, R, Ho, scratch);
-        write_img(dir, "expanded_applied.buffer", k->post_expanded, N, X, Ho, scratch);
-        write_img(dir, "expanded_post_norm.buffer", k->post_expanded_norm_vals, N, X, Ho, scratch);
-        write_img(dir, "transformed_residual.buffer", k->transformed_residual, N, X, Ho, scratch);
-        if (k->output != k->output_activated) write_img(dir, "combined_output.buffer", k->output, N, X, Ho, scratch);
-        write_img(dir, "output_activated.buffer", k->output_activated, N, X, Ho, scratch);
+        if (imgs) {
+            write_img_t(dir, "reduction_applied.buffer", k->post_reduced, N, R, H, scratch, adt);
+            if (!rc) write_img_t(dir, "reduction_activated.buffer", k->post_reduced_activated, N, R, H, scratch, adt);
+            write_img_t(dir, "spatial_applied.buffer", k->post_spatial, N, R, Ho, scratch, adt);
+            if (!rc) write_img_t(dir, "spatial_activated.buffer", k->post_spatial_activated, N, R, Ho, scratch, adt);
+            write_img_t(dir, "expanded_applied.buffer", k->post_expanded, N, X, Ho, scratch, adt);
+            write_img(dir, "expanded_post_norm.buffer", k->post_expanded_norm_vals, N, X, Ho, scratch); /* FULL policy: fp32 */
+            write_img_t(dir, "transformed_residual.buffer", k->transformed_residual, N, X, Ho, scratch, adt);
+            if (k->output != k->output_activated) write_img_t(dir, "combined_output.buffer", k->output, N, X, Ho, scratch, is_deriv ? adt : MID_F32);
+            write_img_t(dir, "output_activated.buffer", k->output_activated, N, X, Ho, scratch, adt);
+        }
         free(dir);
         const char *bn[4] = {"reduced", "spatial", "expanded", "projected"};
         const Cache_BatchNorm *kc[4] = {k->norm_post_reduced, k->norm_post_spatial, k->norm_post_expanded, k->norm_post_projection};
@@ -113,6 +132,7 @@ static void dump_activations(int dump_id, Train_ResNet *t, Activations *a, int i
     write_dev(base, "final_avg_pool.buffer", a->final_conv_output_pooled, (size_t)N * d->final_depth);
     if (!is_deriv) write_dev(base, "fc_output.buffer", a->linear_output, (size_t)N * d->output);
     mid_free(scratch);
+    mid_free(g_widen); g_widen = NULL;
     free(base);
 }
 /* resnet.cu:2682-2753 */
@@ -186,7 +206,7 @@ void overwrite_model_params(Train_ResNet *t, int dump_id, const char *special_di
             if (asprintf(&path, "%s/%s/%08d/%s/%03d.buffer", root_of(t), special_dir, dump_id, names[s], i) < 0) continue;
             FILE *fp = fopen(path, "rb");
             if (fp) {
-                if (fread(host, sizeof(float), sz, fp) == sz) mi_copy_to_device(sets[s]->locations[i], host, sz * sizeof(float));
+                if (fread(host, sizeof(float), sz, fp) == sz) mi_copy_to_device(sets[s]->locations[i], host, sz * sizeof(float)); /* marks the re-laid weights dirty */
                 fclose(fp);
             } else fprintf(stderr, "resnet_mi: missing %s\n", path);
             free(path);

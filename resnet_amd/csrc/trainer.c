@@ -985,6 +985,17 @@ void update_parameters(Train_ResNet *t) {
     t->cur_mean_decay = cur_b1;
     t->cur_var_decay = cur_b2;
 }
+/* end of an epoch as the reference's main() does it (resnet.cu:3410-3421): loss_per_epoch = the epoch's SUMMED loss,
+ * accuracy_per_epoch = fraction right, data source rewound to the first shard, cur_epoch advanced */
+void mi_trainer_end_epoch(Train_ResNet *t, float epoch_loss, float epoch_n_wrong, float total_images_per_epoch) {
+    if (t->cur_epoch >= 0 && t->cur_epoch < (t->n_epochs > 0 ? t->n_epochs : 1)) {
+        t->loss_per_epoch[t->cur_epoch] = epoch_loss;
+        t->accuracy_per_epoch[t->cur_epoch] = (total_images_per_epoch - epoch_n_wrong) / total_images_per_epoch;
+    }
+    t->cur_batch->cur_shard_id = -1;
+    t->cur_batch->cur_batch_in_shard = -1;
+    t->cur_epoch += 1;
+}
 /* check_errors on demand (resnet.cu:2879-2907): waits for the device and reads the flag of the last update */
 int mi_trainer_check_errors(Train_ResNet *t) {
     MiCtx *c = ctx_of(t);

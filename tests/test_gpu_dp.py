@@ -1,0 +1,193 @@
+"""Data-parallel path on the GPU, through PRODUCT code.
+
+* DP-2 emulated on one GPU: two Trainers (rank 0 / rank 1 slices of the global batch, the seeds bench.py gives the ranks)
+  run forward / backward; their gradient arenas are summed on the host -- what ncclAllReduce(ncclSum) does -- and injected
+  into both; update_parameters then must give, on both replicas, what the oracle gives for "2 BN groups of N images,
+  summed gradients, one Adam step" (the DP parity definition of SURVEY 8e; BN statistics per replica).
+* The RCCL launches with a one-rank communicator at the benchmark network's real bucket geometry (32 MB buckets over the
+  190.3 MB arena): the buckets issued by backwards_pass are exactly mi_debug_dp_plan's, per-bucket Adam gives bit-identical
+  parameters to the single-launch path.
+* Two real ranks over RCCL when the box has two GPUs (skipped VISIBLY otherwise: the builder's boxes have one)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import synth
+from util import rel_l2
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HYPER = dict(lr=1e-4, wd=0.0, b1=0.9, b2=0.999, eps=1e-7)
+
+
+def _trainer(dims, batch, params):
+    from resnet_amd import Trainer
+    from resnet_amd import binding as B
+    tr = Trainer(dims, batch, **HYPER)
+    if tr.L.mi_device_count() < 1:
+        pytest.fail("no HIP device: this test must run on the MI355X box")
+    tr.set_params(params)
+    tr.source_host(B.MI_LAYOUT_NHWC)
+    return tr
+
+
+@pytest.mark.parametrize("cfg", ["C1", "C1S"])
+def test_dp2_emulated_on_one_gpu_matches_two_bn_groups(oracle, cfg):
+    from oracle.oracle_py import OracleNet
+    from resnet_amd import dp
+    dims, per = (synth.C1_DIMS, 4) if cfg == "C1" else (synth.C1S_DIMS, 3)
+    params = synth.make_params(dims, perturb_bn=True)
+    trs = [_trainer(dims, per, params) for _ in range(2)]
+    nets = [OracleNet(oracle, dims, per) for _ in range(2)]
+    try:
+        for net in nets:
+            net.set_hyper(HYPER["lr"], HYPER["wd"], HYPER["b1"], HYPER["b2"], HYPER["eps"])
+            for i, p in enumerate(params):
+                net.param(i)[:] = p
+        for step in range(2):
+            for rank in range(2):
+                si, sl = dp.rank_seeds(rank)
+                im, lab = synth.make_batch(dims, per, step=step, seed_img=si, seed_lab=sl)
+                nets[rank].set_batch(im, lab); nets[rank].forward(); nets[rank].backward()
+                trs[rank].fill_host_batch(im, lab); trs[rank].load_new_batch(); trs[rank].forward(); trs[rank].backward()
+                trs[rank].check()
+            n = nets[0].n_locations
+            # the exchange step: SUM, no averaging (resnet.cu:1806-1811)
+            gsum = [trs[0].get("grads", i) + trs[1].get("grads", i) for i in range(n)]
+            osum = [nets[0].grad(i) + nets[1].grad(i) for i in range(n)]
+            # second step: the replicas start from parameters that differ from the oracle's in the 7th digit (Adam's first steps
+            # are ~lr * sign(g)), and a ReLU gate that sits on such a difference moves every gradient upstream of it by
+            # 1e-3..1e-2 -- hence the wider band there; the parameters stay within 1e-5 (1e-4 after two updates: an Adam step is ~lr in every coordinate whatever the gradient's size)
+            gtol = 1e-4 if step == 0 else 3e-2
+            for i in range(n):
+                assert rel_l2(gsum[i], osum[i]) <= gtol, "summed gradient %d step %d: %.3e" % (i, step, rel_l2(gsum[i], osum[i]))
+            for rank in range(2):
+                for i in range(n):
+                    trs[rank].set("grads", i, gsum[i])
+                    nets[rank].grad(i)[:] = osum[i]
+                trs[rank].update(); nets[rank].update()
+                assert trs[rank].check_errors() == 0
+            for i in range(n):
+                p0, p1 = trs[0].get("params", i), trs[1].get("params", i)
+                assert np.array_equal(p0, p1), "replicas diverged at location %d" % i  # identical Adam on every replica
+                assert rel_l2(p0, nets[0].param(i)) <= (1e-5 if step == 0 else 1e-4), "param %d step %d" % (i, step)
+                assert np.all(trs[0].get("grads", i) == 0)  # the update cleared the arena (resnet.cu:2972-2978)
+    finally:
+        for t in trs:
+            t.close()
+        for net in nets:
+            net.close()
+
+
+def _plan(lib, tr, bucket_bytes):
+    fr, to = (C.c_size_t * 64)(), (C.c_size_t * 64)()
+    n = lib.mi_debug_dp_plan(tr.c_dims, bucket_bytes, fr, to, 64)
+    return [(int(fr[i]), int(to[i])) for i in range(n)]
+
+
+def test_rccl_one_rank_resnet50_bucket_geometry():
+    """the benchmark network, batch 2, 32 MB buckets, one-rank RCCL communicator (all-reduce = identity): the buckets
+    backwards_pass hands to RCCL are the planned ones, and per-bucket Adam == single-launch Adam bit for bit"""
+    from resnet_amd import Trainer
+    from resnet_amd import binding as B
+    dims, batch = synth.R50_DIMS, 2
+    params = synth.make_params(dims, perturb_bn=True)
+    im, lab = synth.make_batch(dims, batch, step=0)
+    results = []
+    for with_comm in (False, True):
+        tr = _trainer(dims, batch, params)
+        try:
+            if with_comm:
+                nbytes = tr.L.mi_dp_unique_id_bytes()
+                uid = (C.c_char * nbytes)()
+                assert tr.L.mi_dp_get_unique_id(uid, nbytes) == 0, tr.error()
+                assert tr.L.mi_dp_init(tr.t, 0, 1, uid, nbytes) == 0, tr.error()
+                tr.L.mi_dp_set_bucket_bytes(tr.t, 32 << 20)
+            tr.fill_host_batch(im, lab); tr.load_new_batch(); tr.forward(); tr.backward(); tr.check()
+            if with_comm:
+                fr, to = (C.c_size_t * 64)(), (C.c_size_t * 64)()
+                n = tr.L.mi_debug_last_buckets(tr.t, fr, to, 64)
+                issued = [(int(fr[i]), int(to[i])) for i in range(n)]
+                assert issued == _plan(tr.L, tr, 32 << 20) and len(issued) >= 3
+                assert issued[0][1] == tr.L.mi_debug_arena_floats(tr.c_dims) and issued[-1][0] == 0
+            tr.L.mi_device_synchronize()
+            grads = [tr.get("grads", i) for i in range(tr.n_locations)]
+            tr.update()
+            assert tr.check_errors() == 0
+            results.append((grads, [tr.get("params", i) for i in range(tr.n_locations)]))
+        finally:
+            tr.close()
+    for a, b in zip(results[0][0], results[1][0]):
+        assert np.array_equal(a, b)
+    for a, b in zip(results[0][1], results[1][1]):
+        assert np.array_equal(a, b)
+
+
+RANK_WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import synth
+import torch.distributed as dist
+from resnet_amd import Trainer, dp, binding as B
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+dist.init_process_group("gloo", rank=rank, world_size=world)
+dims, per = synth.C1S_DIMS, 3
+tr = Trainer(dims, per, lr=1e-4, wd=0.0, b1=0.9, b2=0.999, eps=1e-7, device=rank)
+tr.set_params(synth.make_params(dims, perturb_bn=True))
+tr.source_host(B.MI_LAYOUT_NHWC)
+dp.init_data_parallel(tr, dist, rank, world, bucket_mb=1)
+tr.L.mi_dp_set_bucket_bytes(tr.t, 256 << 10)
+si, sl = dp.rank_seeds(rank)
+im, lab = synth.make_batch(dims, per, step=0, seed_img=si, seed_lab=sl)
+tr.fill_host_batch(im, lab); tr.load_new_batch(); tr.forward(); tr.backward(); tr.check()
+tr.L.mi_device_synchronize()
+grads = [tr.get("grads", i) for i in range(tr.n_locations)]
+tr.update(); assert tr.check_errors() == 0
+np.savez(sys.argv[2] + ".%d.npz" % rank, *(grads + [tr.get("params", i) for i in range(tr.n_locations)]))
+dist.barrier(); tr.close(); dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_over_rccl(oracle, tmp_path):
+    from oracle.oracle_py import OracleNet
+    from resnet_amd import binding as B
+    from resnet_amd import dp
+    if B.load().mi_device_count() < 2:
+        pytest.skip("needs 2 GPUs on one node: multi-rank ncclCommInitRank / ncclAllReduce over xGMI is NOT covered on this box")
+    script, out = tmp_path / "w.py", str(tmp_path / "r")
+    script.write_text(RANK_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                           "--master-port", "29655", str(script), ROOT, out], env=env, timeout=600)
+    dims, per = synth.C1S_DIMS, 3
+    params = synth.make_params(dims, perturb_bn=True)
+    nets = [OracleNet(oracle, dims, per) for _ in range(2)]
+    try:
+        for rank, net in enumerate(nets):
+            net.set_hyper(1e-4, 0.0, 0.9, 0.999, 1e-7)
+            for i, p in enumerate(params):
+                net.param(i)[:] = p
+            si, sl = dp.rank_seeds(rank)
+            im, lab = synth.make_batch(dims, per, step=0, seed_img=si, seed_lab=sl)
+            net.set_batch(im, lab); net.forward(); net.backward()
+        n = nets[0].n_locations
+        osum = [nets[0].grad(i) + nets[1].grad(i) for i in range(n)]
+        for i in range(n):
+            nets[0].grad(i)[:] = osum[i]
+        nets[0].update()
+        got = [np.load(out + ".%d.npz" % r) for r in range(2)]
+        for i in range(n):
+            g0, g1 = got[0]["arr_%d" % i], got[1]["arr_%d" % i]
+            assert np.array_equal(g0, g1), "ranks hold different reduced gradients at %d" % i
+            assert rel_l2(g0, osum[i]) <= 1e-4
+            assert np.array_equal(got[0]["arr_%d" % (n + i)], got[1]["arr_%d" % (n + i)])
+            assert rel_l2(got[0]["arr_%d" % (n + i)], nets[0].param(i)) <= 1e-5
+    finally:
+        for net in nets:
+            net.close()

@@ -93,38 +93,106 @@ def test_product_does_not_touch_the_oracle():
     assert "liboracle" not in deps
 
 
-DP_WORKER = r'''
+def _arena_offsets(dims):
+    """float offsets of every locations[] tensor in the product's parameter-shaped arenas: carve order of
+    init_model_parameters (resnet.cu:838-943), each tensor aligned up to 64 floats (trainer.c ARENA_ALIGN)"""
+    import synth
+    sizes = [size for size, _, _ in synth.location_table(dims)]
+    offs, off = [], 0
+    for sz in sizes:
+        offs.append(off)
+        off += (sz + 63) // 64 * 64
+    return offs, sizes, off
+
+
+def _dp_plan(lib, dims, bucket_bytes):
+    import ctypes as C
+    from resnet_amd import binding as B
+    flags = (C.c_int * max(dims["n_conv_blocks"], 1))(*dims["is_block_spatial_reduction"])
+    d = lib.init_dimensions(dims["input"], dims["init_kernel_dim"], dims["init_conv_filters"], dims["init_conv_stride"],
+                            dims["init_maxpool_dim"], dims["init_maxpool_stride"], dims["n_conv_blocks"], flags,
+                            dims["final_depth"], dims["output"])
+    fr, to = (C.c_size_t * 64)(), (C.c_size_t * 64)()
+    n = lib.mi_debug_dp_plan(d, bucket_bytes, fr, to, 64)
+    return [(int(fr[i]), int(to[i])) for i in range(n)], int(lib.mi_debug_arena_floats(d)), flags
+
+
+def test_dp_bucket_plan_resnet50_32mb():
+    """host-only (mi_debug_dp_plan, the arithmetic backwards_pass itself uses): for the reference-defined ResNet-50 with
+    32 MB buckets the buckets tile the 190.3 MB gradient arena exactly once, FC side first (the order update_parameters
+    walks, resnet.cu:2952), every cut falls on a tensor boundary (no tensor is split across two all-reduces), and every
+    bucket but the last is at least one bucket long"""
+    import synth
+    from resnet_amd import binding as B
+    lib = B.load()
+    dims = synth.R50_DIMS
+    plan, arena, _ = _dp_plan(lib, dims, 32 << 20)
+    offs, sizes, total = _arena_offsets(dims)
+    assert arena == total and sum(sizes) == 47576128 and len(sizes) == 160
+    assert plan[0][1] == arena and plan[-1][0] == 0
+    for (f0, t0), (f1, t1) in zip(plan, plan[1:]):
+        assert t1 == f0 and f1 < f0  # contiguous, descending, no overlap, no gap
+    for f, t in plan:
+        assert f in offs, "bucket boundary %d splits a tensor" % f
+    assert all((t - f) * 4 >= (32 << 20) for f, t in plan[:-1])
+    # cuts exist only where a whole block's gradients are final, and b13's block holds the 75 MB projection weight: 4 buckets
+    # (44 / 91 / 45 / 10 MB); the LAST one -- stem + blocks 0-2, what the next forward needs first -- is the small one
+    assert 3 <= len(plan) <= 7, plan
+    assert (plan[-1][1] - plan[-1][0]) * 4 < (32 << 20)
+    assert plan[0][0] <= offs[-1]  # the first bucket holds the FC gradient
+    # tiny buckets: one cut per block + FC + stem side, still an exact tiling
+    plan2, _, _ = _dp_plan(lib, dims, 1)
+    assert len(plan2) == dims["n_conv_blocks"] + 2 and plan2[0][1] == arena and plan2[-1][0] == 0
+    assert all(a[0] == b[1] for a, b in zip(plan2, plan2[1:]))
+
+
+DP_WORKER = r"""
 import os, sys
 import numpy as np
 import torch.distributed as dist
 import torch
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
-import synth
+import synth, test_host
 from oracle.oracle_py import Oracle, OracleNet
-from resnet_amd import dp
+from resnet_amd import dp, binding as B
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 raw = dp.exchange_unique_id(dist, rank, 128, lambda: bytes(range(128)))
 assert raw == bytes(range(128))
-dims, per = synth.C1_DIMS, 2
+lib = B.load()
+dims, per = synth.C1S_DIMS, 2
+# PRODUCT code: the arena layout and the bucket plan every rank derives for itself must agree across ranks
+plan, arena, _ = test_host._dp_plan(lib, dims, 256 << 10)
+offs, sizes, total = test_host._arena_offsets(dims)
+assert arena == total
+t = torch.tensor([arena] + [x for b in plan for x in b], dtype=torch.int64)
+t0 = t.clone(); dist.broadcast(t0, src=0)
+assert torch.equal(t, t0), "ranks disagree on the bucket plan"
+# the checker: this rank's gradients (its own slice of the global batch, its own BN statistics)
 o = Oracle("f32"); net = OracleNet(o, dims, per)
 params = synth.make_params(dims, perturb_bn=True)
 for i, p in enumerate(params): net.param(i)[:] = p
 si, sl = dp.rank_seeds(rank)
 im, lab = synth.make_batch(dims, per, seed_img=si, seed_lab=sl)
 net.set_batch(im, lab); net.forward(); net.backward()
-out = []
+g = torch.zeros(arena, dtype=torch.float32)
 for i in range(net.n_locations):
-    g = torch.from_numpy(net.grad(i).copy())
-    dist.all_reduce(g, op=dist.ReduceOp.SUM)   # what ncclAllReduce(ncclSum) does to the gradient arena
-    out.append(g.numpy())
+    g[offs[i]:offs[i] + sizes[i]] = torch.from_numpy(net.grad(i).copy().ravel())
+# what backwards_pass hands to ncclAllReduce(ncclSum): the product's buckets, in the product's order, in place
+for f, to in plan:
+    dist.all_reduce(g[f:to], op=dist.ReduceOp.SUM)
 if rank == 0:
-    np.savez(sys.argv[2], *out)
+    np.savez(sys.argv[2], arena=g.numpy(), plan=np.array(plan))
 dist.barrier(); dist.destroy_process_group()
-'''
+"""
 
 
-def test_data_parallel_semantics_gloo_world2(tmp_path):
+def test_dp_bucket_plan_allreduce_gloo_world2(tmp_path):
+    """world_size 2 on gloo (CPU).  What runs through PRODUCT code here: the rendezvous helpers, the per-rank stream seeds,
+    the gradient-arena layout and the bucket plan (mi_debug_dp_plan = the arithmetic of backwards_pass), which must be
+    identical on every rank and tile the arena exactly once.  The gradients themselves come from the CPU oracle (there is no
+    GPU here); all-reducing them bucket by bucket over the product's plan must equal the oracle's "2 BN groups, summed
+    gradients" statement (SURVEY 8e).  The RCCL launches themselves are covered on the GPU (tests/test_gpu_dp.py)."""
     import synth
     from oracle.oracle_py import Oracle, OracleNet
     from resnet_amd import dp
@@ -134,11 +202,12 @@ def test_data_parallel_semantics_gloo_world2(tmp_path):
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                            "--master-addr", "127.0.0.1", "--master-port", "29653", str(script), ROOT, str(out)], env=env, timeout=600)
     got = np.load(out)
-    # single-process statement of the same thing: two BN groups of 2 images, gradients summed
-    dims, per = synth.C1_DIMS, 2
+    dims, per = synth.C1S_DIMS, 2
+    offs, sizes, total = _arena_offsets(dims)
+    assert len(got["plan"]) >= 3  # several buckets at this size: the per-bucket path was exercised
     o = Oracle("f32")
     params = synth.make_params(dims, perturb_bn=True)
-    total = None
+    want = np.zeros(total, np.float32)
     for rank in range(2):
         net = OracleNet(o, dims, per)
         for i, p in enumerate(params):
@@ -148,11 +217,10 @@ def test_data_parallel_semantics_gloo_world2(tmp_path):
         net.set_batch(im, lab)
         net.forward()
         net.backward()
-        g = [net.grad(i).copy() for i in range(net.n_locations)]
-        total = g if total is None else [a + b for a, b in zip(total, g)]
+        for i in range(net.n_locations):
+            want[offs[i]:offs[i] + sizes[i]] += net.grad(i).ravel()
         net.close()
-    for i, t in enumerate(total):
-        assert np.array_equal(got["arr_%d" % i], t), "location %d" % i
+    assert np.array_equal(got["arena"], want)
 
 
 def test_conv_launch_planners_on_the_benchmark_shapes():
