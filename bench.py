@@ -1,14 +1,21 @@
 #!/usr/bin/env python3
-"""bench.py -- images/sec of the reference-defined ResNet-50 training step (fp32, 224x224, batch 256 per GPU)
-on N MI355X, through the drop-in C-ABI (load_new_batch -> forward_pass -> host loss -> backwards_pass ->
-update_parameters: the loop of resnet.cu:3340-3402).  Synthetic seeded data resident in HBM, random-init
-weights.  One JSON line on rank 0, with a `roofline` object for the dominant kernel family (HIP events
-around every launch of it, on the launch stream) and a `cpu_baseline` object (the CPU oracle timed on
-this host on a bounded sample; the reference has no CPU path of its own).
+"""bench.py -- images/sec of the reference-defined ResNet-50 training step (224x224, batch 256 per GPU) on N MI355X,
+through the drop-in C-ABI (load_new_batch -> forward_pass -> host loss -> backwards_pass -> update_parameters: the loop
+of resnet.cu:3340-3402).  Synthetic seeded data resident in HBM, random-init weights.  One JSON line on rank 0.
 
-  python bench.py --gpus 1 --steps 10 --warmup 3
+  python bench.py --gpus 1 --steps 10 --warmup 3                      fp32: BASELINE.json's metric (configs[2])
+  python bench.py --dtype bf16                                        bf16 activations / fp32 accumulate (configs[4])
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W
+         bench.py --gpus N --steps K --warmup W                       data parallel, RCCL all-reduce of the gradients
+
+What the line carries besides the contract's fields:
+  roofline       the dominant kernel family, HIP events around every launch of it on its launch stream INSIDE the timed
+                 region (the other families are not bracketed there: ~1200 event records per step cost 2-3 %);
+                 roofline.families: every family, from K FURTHER steps with every launch bracketed, run right after the
+                 timed region (their own ms/step is given: it shows what the bracketing costs)
+  value_h2d_inclusive   K further steps with the batch handed over in pinned host memory every step (the reference's own
+                 blocking copy, resnet.cu:1315-1316: 154 MB per step over PCIe) -- never `value`
+  cpu_baseline   the CPU oracle (a port: the reference has no CPU path) on this host, bounded samples
 """
 import argparse
 import ctypes as C
@@ -20,40 +27,64 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP32_PEAK_TFLOPS = 157.3  # gfx950 fp32: vector FMA rate == fp32 MFMA rate (MI355X_MICROARCH.md)
+FP32_PEAK_TFLOPS = 157.3   # gfx950 fp32: vector FMA rate == fp32 MFMA rate (MI355X_MICROARCH.md)
+BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md; AMD's 5 PF figure includes 2:1 sparsity)
 HBM_PEAK_GBS = 8000.0
-FAMILIES = {0: "direct conv 7x7 stem / untiled 3x3 fwd+dgrad (dconv_kernel, VALU)", 1: "direct conv wgrad (wgradC/wgrad_kernel, VALU)",
-            2: "1x1 conv / FC GEMM (igemm_kernel<*,1,1,*> / gemm_mfma_kernel, fp32 MFMA)", 3: "batch norm fwd+bwd",
-            5: "3x3 conv fwd+dgrad+wgrad incl. the 3x3-s2 projections (igemm_kernel<*,3,*,*>, implicit GEMM on fp32 MFMA)"}
+FAMILIES_F32 = {0: "direct conv 7x7 stem / untiled 3x3 fwd+dgrad (dconv_kernel, VALU)", 1: "direct conv wgrad (wgradC/wgrad_kernel, VALU)",
+                2: "1x1 conv / FC GEMM (igemm_kernel<*,1,1,*> / gemm_mfma_kernel, fp32 MFMA)", 3: "batch norm fwd+bwd",
+                5: "3x3 conv fwd+dgrad+wgrad incl. the 3x3-s2 projections (igemm_kernel<*,3,*,*>, implicit GEMM on fp32 MFMA)"}
+FAMILIES_BF16 = {0: "7x7 stem fwd (dconv_kernel, fp32 VALU)", 1: "7x7 stem wgrad (wgrad_kernel, fp32 VALU)",
+                 2: "1x1 conv (bgemm_kernel<*,1,1,*>, bf16 MFMA) + FC GEMM (fp32 MFMA)", 3: "batch norm fwd+bwd (bf16 tensors, fp32 math)",
+                 5: "3x3 conv fwd+dgrad+wgrad incl. the 3x3-s2 projections (bgemm_kernel<*,3,*,*>, implicit GEMM on bf16 MFMA)"}
+PMC_KEY = {0: "dconv", 1: "wgradC", 2: "gemm", 3: "bn", 5: "igemm3x3"}
 
 
-def cpu_baseline(seconds_budget=30.0):
-    """The oracle (a CPU port: the reference has no CPU path) on a bounded sample of the same workload:
-    reference-defined ResNet-50, 224x224, fwd + bwd + Adam, batch 6, OpenMP over independent outputs."""
+def _time_oracle(o, dims, batch, threads):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import synth
-    from oracle.oracle_py import Oracle, OracleNet
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = min(cores, 32)
-    o = Oracle("f32")
-    o.set_threads(cores)
-    dims, batch = synth.R50_DIMS, 6  # ~10-15 s of CPU work on the GPU box's host cores
+    from oracle.oracle_py import OracleNet
+    o.set_threads(threads)
     net = OracleNet(o, dims, batch)
-    params = synth.make_params(dims)
-    for i, p in enumerate(params):
+    for i, p in enumerate(synth.make_params(dims)):
         net.param(i)[:] = p
     im, lab = synth.make_batch(dims, batch)
     net.set_batch(im, lab)
     t0 = time.time()
-    net.forward()
-    net.loss()
-    net.backward()
-    net.update()
+    net.forward(); net.loss(); net.backward(); net.update()
     dt = time.time() - t0
     net.close()
-    return {"value": batch / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+    return dt
+
+
+def cpu_baseline():
+    """The oracle (a CPU port: the reference has no CPU path) on bounded samples of the same workload, timed on this
+    host: the reference-defined ResNet-50 at batch 4 on every core the process may use (the headline `value`), config 1
+    (BASELINE configs[0]) in full on one thread and on all of them.  A single-thread ResNet-50 step is not run: at the
+    per-thread rate measured here it would take over a minute per image."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import synth
+    from oracle.oracle_py import Oracle
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = visible
+    try:  # a container's CPU share (cgroup v2 quota) is what this process can really use
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            cores = max(1, min(visible, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        pass
+    cores = min(cores, 32)  # the oracle's OpenMP loops stop scaling (and a GPU box gives one job ~16 cores of the 256 it shows)
+    o = Oracle("f32")
+    c1_1 = min(_time_oracle(o, synth.C1_DIMS, synth.C1_BATCH, 1) for _ in range(3))
+    c1_n = min(_time_oracle(o, synth.C1_DIMS, synth.C1_BATCH, cores) for _ in range(3))
+    batch = 4
+    dt = _time_oracle(o, synth.R50_DIMS, batch, cores)
+    return {"value": round(batch / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": "1 full training step (fwd+loss+bwd+Adam) of the reference-defined ResNet-50 fp32 224x224 at batch %d, "
-                      "oracle/liboracle_f32.so with %d OpenMP threads, %.1f s" % (batch, cores, dt)}
+                      "oracle/liboracle_f32.so with %d OpenMP threads (`cores` = threads used; the host shows %d CPUs), %.1f s" % (batch, cores, visible, dt),
+            "config1_images_per_sec_1_thread": round(synth.C1_BATCH / c1_1, 2),
+            "config1_images_per_sec_all_threads": round(synth.C1_BATCH / c1_n, 2),
+            "config1_sample": "config 1 (1 block, batch 4, 32x32): one full step, best of 3, %.1f ms on 1 thread, %.1f ms on %d" % (c1_1 * 1e3, c1_n * 1e3, cores),
+            "resnet50_1_thread": "not run (bounded sample: ~%.0f s per image at the per-thread rate above)" % (dt * cores / batch)}
 
 
 def main():
@@ -63,7 +94,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-prof", action="store_true", help="disable the per-kernel HIP-event timing")
+    ap.add_argument("--no-prof", action="store_true", help="no per-kernel HIP-event timing at all (and no extra instrumented steps)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the further steps behind the timed region (families, H2D-inclusive)")
     ap.add_argument("--bucket-mb", type=int, default=32)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="storage type of activations (bf16 = BASELINE configs[4]); arithmetic is fp32 either way")
     ap.add_argument("--policy", choices=["fast", "recompute_bn"], default="fast", help="what backward keeps from forward (mi_trainer_set_store_policy)")
@@ -92,12 +124,15 @@ def main():
         import torch.distributed as dist  # rendezvous + barrier + max-reduce only (gloo); collectives are RCCL in C
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    bf16 = args.dtype == "bf16"
+    FAMILIES = FAMILIES_BF16 if bf16 else FAMILIES_F32
     dims = resnet_dims()
     tr = Trainer(dims, args.batch, lr=1e-4, wd=0.0, b1=0.9, b2=0.999, eps=1e-7, seed=1236, device=local_rank)
     if args.policy == "recompute_bn":
         tr.set_store_policy(B.MI_STORE_RECOMPUTE_BN)
-    if args.dtype == "bf16":
+    if bf16:
         tr.set_dtype(B.MI_DTYPE_BF16)
+    act_bytes, dev_bytes = tr.activation_bytes(), tr.device_bytes()
     # every rank draws its own slice of the global batch: distinct image/label streams per rank
     from resnet_amd import dp
     tr.source_synthetic(*dp.rank_seeds(rank), pool_batches=2)
@@ -117,90 +152,125 @@ def main():
             st[fam] = (n.value, ms.value, fl.value, by.value)
         return st
 
+    def timed(k):
+        barrier()
+        t0 = time.perf_counter()
+        ls = [tr.step()[0] for _ in range(k)]
+        lib.mi_device_synchronize()
+        dt = time.perf_counter() - t0
+        barrier()
+        tr.check()
+        if dist is not None:
+            import torch
+            tt = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt[0])
+        return dt, ls
+
     losses = []
     prof = not args.no_prof
-    warm_stats, warm_steps = {}, 0
+    warm_stats = {}
     for w in range(args.warmup):
-        # the last warm-up step is timed per kernel family (HIP events around every launch cost ~3% of a step, so in
-        # the timed region only the dominant family found here is bracketed)
+        # the last warm-up step is bracketed per family only to FIND the dominant one
         if prof and w == args.warmup - 1:
             lib.mi_prof_enable(1)
             lib.mi_prof_reset()
-            warm_steps = 1
         losses.append(tr.step()[0])
     tr.check()
-    dom = 0
+    dom = 5
     if prof:
-        if warm_steps:
+        if args.warmup:
             warm_stats = read_prof()
             dom = max(warm_stats, key=lambda f: warm_stats[f][1])
         lib.mi_prof_enable(1 << dom if dom else 2 | 1)  # family 0 -> mask 1 (value 1 means "all", so add family 1)
         lib.mi_prof_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        losses.append(tr.step()[0])
-    lib.mi_device_synchronize()
-    dt = time.perf_counter() - t0
-    barrier()
-    tr.check()
-    if dist is not None:
-        import torch
-        tt = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt[0])
-
-    fam_stats = {}
-    if prof:
-        fam_stats = read_prof()
-        lib.mi_prof_enable(0)
+    dt, ls = timed(args.steps)          # ---- THE timed region: exactly K steps ----
+    losses += ls
+    dom_stats = read_prof()[dom] if prof else None
     timings = tr.timings()
+
+    fam_stats, dt_fam, dt_h2d = {}, None, None
+    if prof and not args.no_extra:
+        lib.mi_prof_enable(1)
+        lib.mi_prof_reset()
+        dt_fam, _ = timed(args.steps)   # K further steps, every launch of every family bracketed
+        fam_stats = read_prof()
+    lib.mi_prof_enable(0)
+    if not args.no_extra and world == 1:
+        # K further steps with the reference's own data movement: the batch sits in pinned host memory and is copied over
+        # PCIe at the top of every step (blocking, resnet.cu:1315-1316)
+        import numpy as np
+        tr.source_host(B.MI_LAYOUT_NCHW)
+        b = tr.c_batch.contents
+        rng = np.random.default_rng(1234)
+        tr.fill_host_batch(rng.uniform(-124.0, 152.0, size=b.n_images * b.image_size).astype(np.float32),
+                           rng.integers(0, dims["output"], size=b.n_images).astype(np.int32))
+        tr.step()
+        dt_h2d, _ = timed(args.steps)
     tr.close()
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = args.batch * world * args.steps / dt
-        out = {"metric": "images/sec ResNet-50 fp32 224x224 batch256", "value": round(value, 2), "unit": "images/sec",
+        nice = "bf16 activations / fp32 accumulate" if bf16 else "fp32"
+        out = {"metric": "images/sec ResNet-50 %s 224x224 batch256" % ("bf16" if bf16 else "fp32"), "value": round(value, 2), "unit": "images/sec",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "reference-defined ResNet-50 (47.58M params, 3x3-s2 projections, Adam, sum loss), "
-                                      "fp32, 224x224, full training step, batch %d per GPU" % args.batch,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+               "config": {"workload": "reference-defined ResNet-50 (47.58M params, 3x3-s2 projections, Adam, sum loss), %s, 224x224, "
+                                      "full training step, batch %d per GPU%s" % (nice, args.batch, ", store policy RECOMPUTE_BN" if args.policy != "fast" else ""),
                           "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                           "phase_ms_last_step": {"forward": round(timings[1], 3), "backward": round(timings[2], 3),
                                                  "update": round(timings[3], 3)},
-                          "final_loss_per_image": round(losses[-1] / args.batch, 4)}}
-        if fam_stats:
-            n, ms, fl, by = fam_stats[dom]
-            if dom == 3:
-                ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-                roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+                          "final_loss_per_image": round(losses[-1] / args.batch, 4),
+                          "activation_bytes_kept_for_backward": act_bytes, "device_bytes": dev_bytes}}
+        if dt_h2d is not None:
+            out["value_h2d_inclusive"] = round(args.batch * world * args.steps / dt_h2d, 2)
+            out["h2d_note"] = ("%d further steps with the batch in pinned host memory, copied over PCIe at the top of every step "
+                               "(blocking, as resnet.cu:1315-1316): %.3f ms/step; never `value`" % (args.steps, dt_h2d / args.steps * 1e3))
+
+        def roof_of(fam, stat, steps):
+            n, ms, fl, by = stat
+            sec = max(ms, 1e-9) * 1e-3
+            tf, gbs = fl / sec / 1e12, by / sec / 1e9
+            # which roof binds the family: its arithmetic intensity against the machine balance of the pipe it runs on
+            peak_tf = BF16_PEAK_TFLOPS if (bf16 and fam in (2, 5)) else FP32_PEAK_TFLOPS
+            mfma_bound = fl > 0 and (fl / max(by, 1.0)) >= peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
+            r = {"kernel": FAMILIES[fam], "bound": "mfma" if mfma_bound else "hbm", "launches_per_step": round(n / steps, 1),
+                 "ms_per_step": round(ms / steps, 3)}
+            if mfma_bound:
+                r.update({"achieved": round(tf, 2), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(tf / peak_tf, 4), "algorithmic_GB_per_s": round(gbs, 1)})
             else:
-                ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-                roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": None}
-            # HBM traffic of that family from the committed rocprofv3 PMC passes (bench.py cannot run the profiler itself)
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-                key = {0: "dconv", 1: "wgradC", 2: "gemm", 3: "bn", 5: "igemm3x3"}[dom]
-                # the PMC passes count kernel launches, this run counts logical launches (the four concurrent stride-2 dgrad
-                # class kernels are one): convert through bytes per step
-                roof["traffic"] = round(pmc["families"][key]["hbm_GB_per_step_raw"] * 1e9 / (n / args.steps))
-                roof["traffic_note"] = ("HBM bytes per launch (FETCH_SIZE+WRITE_SIZE, separate --pmc passes, profiles/r1_pmc_traffic.json; "
-                                        "4-B/lane gathers: gfx950 FETCH halving uncalibrated, raw value; Infinity-Cache hits are counted); algorithmic bytes per launch: %d" % round(by / max(n, 1)))
-            except Exception:
-                pass
-            roof["kernel"] = FAMILIES[dom]
+                r.update({"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)})
+                if fl > 0:
+                    r["algorithmic_TFLOP_per_s"] = round(tf, 2)
+            return r
+
+        if dom_stats:
+            n, ms, fl, by = dom_stats
+            roof = roof_of(dom, dom_stats, args.steps)
             roof["launches"] = n
             roof["avg_launch_ms"] = round(ms / max(n, 1), 4)
             roof["algorithmic_gflop_per_launch"] = round(fl / max(n, 1) / 1e9, 3)
-            roof["note"] = "fp32 peak 157.3 TFLOP/s is both the vector-FMA and the fp32-MFMA rate on gfx950"
-            if warm_stats:  # whole-step breakdown from the profiled warm-up step (all families bracketed)
-                roof["families_ms_per_step_warmup"] = {FAMILIES[f].split(" (")[0]: round(warm_stats[f][1] / warm_steps, 3) for f in warm_stats}
-                roof["families_tflops_warmup"] = {FAMILIES[f].split(" (")[0]: round(warm_stats[f][2] / max(warm_stats[f][1], 1e-9) / 1e9, 2)
-                                                  for f in warm_stats if warm_stats[f][2] > 0}
-                roof["families_gbs_warmup"] = {FAMILIES[f].split(" (")[0]: round(warm_stats[f][3] / max(warm_stats[f][1], 1e-9) / 1e6, 1)
-                                               for f in warm_stats if warm_stats[f][3] > 0}
+            roof["algorithmic_bytes_per_launch"] = round(by / max(n, 1))
+            roof["traffic"] = None
+            # HBM bytes of that family from the committed rocprofv3 PMC passes (bench.py cannot run the profiler itself)
+            pmc_file = "r2_bf16_pmc_traffic.json" if bf16 else "r2_pmc_traffic.json"
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
+                # the PMC passes count kernel launches, this run counts logical launches: convert through bytes per step
+                roof["traffic"] = round(pmc["families"][PMC_KEY[dom]]["hbm_GB_per_step_raw"] * 1e9 / (n / args.steps))
+                roof["traffic_note"] = ("HBM bytes per launch = FETCH_SIZE + WRITE_SIZE of two separate rocprofv3 --pmc passes over this command at the "
+                                        "same commit (profiles/%s, tools/pmc_traffic.sh); gathers narrower than 16 B per lane: gfx950 FETCH halving "
+                                        "uncalibrated, raw value; Infinity-Cache hits are counted" % pmc_file)
+            except Exception:
+                roof["traffic_note"] = "profiles/%s not present: no PMC traffic for this configuration" % pmc_file
+            roof["note"] = ("fp32 peak 157.3 TFLOP/s is both the vector-FMA and the fp32-MFMA rate on gfx950; bf16 peak 2500 TFLOP/s dense; "
+                            "`achieved` = algorithmic work of the family's launches / their HIP-event durations inside the timed region")
+            if fam_stats:
+                roof["families"] = [roof_of(f, fam_stats[f], args.steps) for f in sorted(fam_stats) if fam_stats[f][0] > 0]
+                roof["families_note"] = ("%d further steps with every launch of every family bracketed by HIP events: %.3f ms/step "
+                                         "(weight gradients run on a second stream next to batch norm, so family times overlap and do not add up to the step)"
+                                         % (args.steps, dt_fam / args.steps * 1e3))
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
