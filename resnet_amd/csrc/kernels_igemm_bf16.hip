@@ -18,6 +18,7 @@
 // Epilogue of forward / dgrad: accumulators are transposed through LDS so that a lane owns one output channel and 32
 // consecutive pixels -> 16-byte (8 x bf16) stores, and the forward pass leaves per-tile batch-norm statistics (count, mean,
 // M2, computed from the fp32 accumulators before rounding) exactly as the fp32 kernel does.
+#include <stdlib.h>
 #include "mi_common.hpp"
 #include "mi_device.h"
 
@@ -31,8 +32,11 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16;
 
 enum { BG_FWD = 0, BG_DGRAD = 1, BG_WGRAD = 2 };
+enum { BGOP_FWD = 0, BGOP_DGRAD = 1, BGOP_WGRAD = 2 };
 #define BG_BK 32
 #define BG_LDB 80 /* bytes per LDS row: 32 bf16 + 16 bytes of padding */
+#define BG_BIAS 256 /* = MI_GUARD (mi_host.h): slack bytes in front of / behind every tensor these kernels read; a tap shift of
+                       up to (W + 1) elements must fit: W <= 120 (mi_bgemm_supported) */
 
 struct BgArgs {
     int N, C, K, H, W, Ho, Wo; // KS x KS, stride S, pad KS/2
@@ -55,7 +59,26 @@ __device__ __forceinline__ uint32_t bg_pack2(float a, float b) { // round to nea
 }
 __device__ __forceinline__ u16 bg_f2bf(float a) { return (u16)(bg_pack2(a, 0.f) & 0xffffu); }
 
-template <int MODE, int KS, int S, int WMW>
+// 16-bit lane masks of one dword from two validity bits
+__device__ __forceinline__ uint32_t bg_lane_mask(uint32_t two_bits) {
+    return ((two_bits & 1u) ? 0x0000ffffu : 0u) | ((two_bits & 2u) ? 0xffff0000u : 0u);
+}
+template <int VW> struct BgVec;
+template <> struct BgVec<8> { typedef u32x4 T; };
+template <> struct BgVec<4> { typedef u32x2 T; };
+template <> struct BgVec<1> { typedef u32x2 T; }; // unused placeholder
+// loads of VW bf16 whose address is only 2-byte aligned (a tap shifts the pixel index by one): gfx950 under ROCm serves them
+// at the streaming rate (tools/ubench/unaligned_load.hip: 5.9 TB/s at every element shift)
+typedef u32x4 __attribute__((aligned(2))) u32x4_u;
+typedef u32x2 __attribute__((aligned(2))) u32x2_u;
+template <int VW> __device__ __forceinline__ typename BgVec<VW>::T bg_ldv(const char *p) {
+    if constexpr (VW == 8) return *(const u32x4_u *)p;
+    else return *(const u32x2_u *)p;
+}
+
+// VW = pixels per operand load: 1 = the element-wise gathers (any plane size); 8 / 4 = 16- / 8-byte loads along the pixels
+// (plane size a multiple of VW; forward with stride 2: output ROW length a multiple of VW), transposed in registers.
+template <int MODE, int KS, int S, int WMW, int VW>
 __global__ void __launch_bounds__(256)
 bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__restrict__ OutV, const u16 *__restrict__ addend,
              const BgArgs g) {
@@ -64,7 +87,18 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
     constexpr int WNC = 32 * TN;
     constexpr int T = KS * KS, PAD = KS / 2;
     constexpr int NA = BM / 64;   // fwd/dgrad: 16-byte loads of A per thread and tile
-    constexpr int NAS = BM / 8;   // wgrad: 2-byte loads of A per thread and tile
+    constexpr int NAS = BM / 8;   // wgrad, VW == 1: 2-byte loads of A per thread and tile
+    constexpr bool VEC = VW > 1;
+    typedef typename BgVec<VW>::T LT;
+    constexpr int LW = VW / 2;    // dwords per vector load
+    // fwd / dgrad vector staging: a unit = VW pixels x 2 channels; 16 channel pairs x (128 / VW) pixel groups per tile
+    constexpr int NU = VEC ? 8 / VW : 1;               // units per thread
+    constexpr bool S2F = MODE == BG_FWD && S == 2;     // forward, stride 2: VW output pixels <- every other one of 2 VW input pixels
+    // wgrad vector staging: a unit = VW pixels of one row; 32 / VW units per 32-pixel row
+    constexpr int NPU = VEC ? 32 / VW : 1;
+    constexpr int RPT = 256 / NPU;                     // rows one pass of the 256 threads covers
+    constexpr int NAU = VEC ? BM / RPT : 1, NBU = VEC ? 128 / RPT : 1;
+    constexpr bool S2W = MODE == BG_WGRAD && S == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char bg_smem[];
     unsigned char *As = bg_smem;                         // [2][BM][80 B]
     unsigned char *Bs = bg_smem + 2 * BM * BG_LDB;       // [2][128][80 B]
@@ -93,48 +127,81 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
     // ---- per-thread staging state (byte offsets; every tensor is < 2^32 bytes: mi_bgemm_supported) ----
     uint32_t b_lane = 0;
     uint32_t mask = 0;
+    uint32_t vb_lane[NU];       // VEC: byte offset of (image, centre pixel of the unit's first column, first channel of the pair)
+    uint64_t vm_lo[NU];         // VEC: validity of the unit's VW pixels, 8 bits per tap, taps 0..7
+    uint32_t vm_hi[NU];         //      tap 8
     int ph = 0, pw = 0, ntaps = 1;
     int ntiles = 0, kend = 0;
     int hf_r[2] = {0, 0}, hf_s[2] = {0, 0}, hf_ok[2] = {0, 0};
     uint32_t hf_c[2] = {0, 0};
     if (MODE == BG_FWD || MODE == BG_DGRAD) {
-        const int j = n0 + (tid & 127);
-        const bool jin = j < g.ncols;
-        const uint32_t jc = jin ? (uint32_t)j : (uint32_t)g.ncols - 1;
-        const uint32_t n = fd_div(jc, g.fdP);
-        const uint32_t p = jc - n * g.P;
-        const uint32_t ho = fd_div(p, g.fdWo), wo = p - ho * g.Wo;
-        const int b_k = 16 * (tid >> 7);
-        if (MODE == BG_FWD) {
-            b_lane = (uint32_t)(n * g.C * g.HW + (S * ho) * g.W + S * wo + b_k * g.HW) * 2u;
-#pragma unroll
-            for (int t = 0; t < T; t++) {
-                const int hi = S * (int)ho - PAD + t / KS, wi = S * (int)wo - PAD + t % KS;
-                if (jin && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) mask |= 1u << t;
-            }
-            ntaps = T;
-            ntiles = T * (g.C / BG_BK);
-        } else if (S == 1) {
-            b_lane = (uint32_t)(n * g.K * g.P + p + b_k * g.P) * 2u;
-#pragma unroll
-            for (int t = 0; t < T; t++) {
-                const int hs = (int)ho + PAD - t / KS, ws = (int)wo + PAD - t % KS;
-                if (jin && hs >= 0 && hs < g.Ho && ws >= 0 && ws < g.Wo) mask |= 1u << t;
-            }
-            ntaps = T;
-            ntiles = T * (g.K / BG_BK);
-        } else {
+        if (MODE == BG_FWD) { ntaps = T; ntiles = T * (g.C / BG_BK); }
+        else if (S == 1) { ntaps = T; ntiles = T * (g.K / BG_BK); }
+        else {
             const int cls = 3 - (int)blockIdx.y; // heaviest class (4 taps) first
             ph = cls >> 1; pw = cls & 1;
-            const int ntw = pw ? 2 : 1;
-            ntaps = (ph ? 2 : 1) * ntw;
-            b_lane = (uint32_t)(n * g.K * g.P + p + b_k * g.P) * 2u;
-            for (int tt = 0; tt < ntaps; tt++) {
-                const int th = tt / ntw, tw = tt - th * ntw;
-                const int dh = (ph && th == 0) ? 1 : 0, dw = (pw && tw == 0) ? 1 : 0;
-                if (jin && (int)ho + dh < g.Ho && (int)wo + dw < g.Wo) mask |= 1u << tt;
-            }
+            ntaps = (ph ? 2 : 1) * (pw ? 2 : 1);
             ntiles = ntaps * (g.K / BG_BK);
+        }
+        // validity of column j's tap t (bit t), and the byte offset of its centre pixel in channel 0 of its image
+        auto column = [&](int j, uint32_t &centre) -> uint32_t {
+            const bool jin = j < g.ncols;
+            const uint32_t jc = jin ? (uint32_t)j : (uint32_t)g.ncols - 1;
+            const uint32_t n = fd_div(jc, g.fdP);
+            const uint32_t p = jc - n * g.P;
+            const uint32_t ho = fd_div(p, g.fdWo), wo = p - ho * g.Wo;
+            uint32_t m = 0;
+            if (MODE == BG_FWD) {
+                centre = (uint32_t)(n * g.C * g.HW + (S * ho) * g.W + S * wo) * 2u;
+#pragma unroll
+                for (int t = 0; t < T; t++) {
+                    const int hi = S * (int)ho - PAD + t / KS, wi = S * (int)wo - PAD + t % KS;
+                    if (jin && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) m |= 1u << t;
+                }
+            } else if (S == 1) {
+                centre = (uint32_t)(n * g.K * g.P + p) * 2u;
+#pragma unroll
+                for (int t = 0; t < T; t++) {
+                    const int hs = (int)ho + PAD - t / KS, ws = (int)wo + PAD - t % KS;
+                    if (jin && hs >= 0 && hs < g.Ho && ws >= 0 && ws < g.Wo) m |= 1u << t;
+                }
+            } else {
+                centre = (uint32_t)(n * g.K * g.P + p) * 2u; // (a, b) itself is always a valid source pixel
+                const int ntw = pw ? 2 : 1;
+                for (int tt = 0; tt < ntaps; tt++) {
+                    const int th = tt / ntw, tw = tt - th * ntw;
+                    const int dh = (ph && th == 0) ? 1 : 0, dw = (pw && tw == 0) ? 1 : 0;
+                    if (jin && (int)ho + dh < g.Ho && (int)wo + dw < g.Wo) m |= 1u << tt;
+                }
+            }
+            return m;
+        };
+        if (!VEC) {
+            uint32_t centre;
+            mask = column(n0 + (tid & 127), centre);
+            b_lane = centre + (uint32_t)(16 * (tid >> 7)) * (uint32_t)(MODE == BG_FWD ? g.HW : g.P) * 2u;
+        } else {
+            const uint32_t plane = (uint32_t)(MODE == BG_FWD ? g.HW : g.P);
+#pragma unroll
+            for (int u = 0; u < NU; u++) {
+                const int col0 = n0 + ((tid >> 4) + 16 * u) * VW;
+                uint64_t lo = 0;
+                uint32_t hi = 0, c0 = 0;
+#pragma unroll
+                for (int e = 0; e < VW; e++) {
+                    uint32_t ce;
+                    const uint32_t m = column(col0 + e, ce);
+                    if (e == 0) c0 = ce;
+#pragma unroll
+                    for (int t = 0; t < 8; t++) lo |= (uint64_t)((m >> t) & 1u) << (8 * t + e);
+                    hi |= ((m >> 8) & 1u) << e;
+                }
+                // a group past the last column decodes to the last column for every element: its mask is 0 and its loads stay in bounds
+                // + BG_BIAS: the lane offset stays non-negative when a tap shift points a few pixels in front of the tensor (its
+                // very first pixels: masked lanes inside the allocation's guard bytes); the base pointer is lowered to match
+                vb_lane[u] = c0 + (uint32_t)(2 * (tid & 15)) * plane * 2u + BG_BIAS;
+                vm_lo[u] = lo; vm_hi[u] = hi;
+            }
         }
     } else {
 #pragma unroll
@@ -154,6 +221,10 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
     // registers of the tile in flight
     u32x4 ra4[NA];
     u16 ra[NAS], rb[16];
+    LT vb[NU][2][S2F ? 2 : 1];              // VEC fwd/dgrad: [unit][channel of the pair][first / second half of a stride-2 span]
+    uint32_t vmask[NU];
+    LT wa[NAU], wb[NBU][S2W ? 2 : 1];       // VEC wgrad
+    uint32_t wmask[NBU];
     int sel_a = 1, sel_b = 1;
     int ld_t = 0, ld_c0 = 0;
     int ld_k0 = (MODE == BG_WGRAD) ? (int)blockIdx.y * g.klen : 0;
@@ -164,40 +235,55 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
             const int t = min(ld_t, ntaps - 1); // the two drain iterations re-read the last tap
             sel_b = (mask >> t) & 1;
             const char *fa, *fb;
-            uint32_t fb_lane;
+            int shift;        // element offset of tap t's source pixel from the centre pixel
             size_t bstride;
             if (MODE == BG_FWD) {
                 const int r = KS == 3 ? (t * 11) >> 5 : 0, s = t - KS * r;
                 fa = (const char *)(Aop + ((size_t)(t * (g.C / BG_BK) + ld_c0 / BG_BK) * g.K + m0) * BG_BK);
                 fb = (const char *)(Bop + (size_t)ld_c0 * g.HW);
-                fb_lane = b_lane + (uint32_t)(sel_b * ((r - PAD) * g.W + (s - PAD)) * 2); // outside: centre pixel, stored as 0
+                shift = (r - PAD) * g.W + (s - PAD);
                 bstride = (size_t)g.HW * 2;
                 ld_c0 += BG_BK;
                 if (ld_c0 == g.C) { ld_c0 = 0; ld_t++; }
             } else {
-                int wt, doff;
+                int wt;
                 if (S == 1) {
                     const int r = KS == 3 ? (t * 11) >> 5 : 0, s = t - KS * r;
                     wt = t;
-                    doff = (PAD - r) * g.Wo + (PAD - s);
+                    shift = (PAD - r) * g.Wo + (PAD - s);
                 } else {
                     const int th = pw ? t >> 1 : t, tw = pw ? t & 1 : 0;
                     const int r = ph ? 2 * th : 1, s = pw ? 2 * tw : 1;
                     wt = 3 * r + s;
-                    doff = (ph & (th ^ 1)) * g.Wo + (pw & (tw ^ 1));
+                    shift = (ph & (th ^ 1)) * g.Wo + (pw & (tw ^ 1));
                 }
                 fa = (const char *)(Aop + ((size_t)(wt * (g.K / BG_BK) + ld_c0 / BG_BK) * g.C + m0) * BG_BK);
                 fb = (const char *)(Bop + (size_t)ld_c0 * g.P);
-                fb_lane = b_lane + (uint32_t)(sel_b * doff * 2);
                 bstride = (size_t)g.P * 2;
                 ld_c0 += BG_BK;
                 if (ld_c0 == g.K) { ld_c0 = 0; ld_t++; }
             }
+            if (!VEC) {
+                const uint32_t fb_lane = b_lane + (uint32_t)(sel_b * shift * 2); // outside: centre pixel, stored as 0
 #pragma unroll
-            for (int q = 0; q < 16; q++) rb[q] = ldg16(fb + (size_t)q * bstride, fb_lane);
+                for (int q = 0; q < 16; q++) rb[q] = ldg16(fb + (size_t)q * bstride, fb_lane);
+            } else {
+#pragma unroll
+                for (int u = 0; u < NU; u++) {
+                    const uint32_t m = t < 8 ? (uint32_t)(vm_lo[u] >> (8 * t)) & 0xffu : vm_hi[u];
+                    vmask[u] = m;
+                    // no valid pixel at all: stay on the centre (always inside the tensor)
+                    const uint32_t off = vb_lane[u] + (uint32_t)((m ? shift : 0) * 2);
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        vb[u][c][0] = bg_ldv<VW>(fb - BG_BIAS + (size_t)c * bstride + off);
+                        if (S2F) vb[u][c][1] = bg_ldv<VW>(fb - BG_BIAS + (size_t)c * bstride + off + VW * 2);
+                    }
+                }
+            }
 #pragma unroll
             for (int q = 0; q < NA; q++) ra4[q] = *(const u32x4 *)(fa + (size_t)(tid + 256 * q) * 16);
-        } else {
+        } else if (!VEC) {
             const int kk = ld_k0 + (tid & 31);
             sel_a = kk < kend;
             const uint32_t kc = sel_a ? (uint32_t)kk : (uint32_t)kend - 1;
@@ -221,27 +307,120 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
                 for (int q = 0; q < 8; q++) rb[8 * h + q] = ldg16((const char *)Bop + (size_t)(8 * q) * g.HW * 2, fb_lane);
             }
             ld_k0 += BG_BK;
+        } else {
+            // VW consecutive pixels of one image per load: dY rows as they lie, x rows shifted by the tap (stride 2: every other
+            // pixel of a 2 VW span); out-of-image pixels are zeroed by per-element masks when the tile goes to LDS
+            constexpr uint32_t ones = (1u << VW) - 1u;
+            const int part = tid % NPU, row0 = tid / NPU;
+            const int kk = ld_k0 + part * VW;
+            sel_a = kk < kend;
+            const uint32_t kc = sel_a ? (uint32_t)kk : (uint32_t)(kend - VW);
+            const uint32_t n = fd_div_ge2(kc, g.fdP);
+            const uint32_t pp = kc - n * g.P;
+            const uint32_t ho0 = fd_div_ge2(pp, g.fdWo), wo0 = pp - ho0 * g.Wo;
+            const char *fa = (const char *)(Aop + (size_t)m0 * g.P);
+            const uint32_t fa_lane = (n * (uint32_t)(g.K * g.P) + pp + (uint32_t)row0 * g.P) * 2u;
+#pragma unroll
+            for (int q = 0; q < NAU; q++) wa[q] = *(const LT *)(fa + (size_t)(RPT * q) * g.P * 2 + fa_lane);
+            // the VW pixels may run over the end of an output row (stride 1 only: stride 2 needs rows of a multiple of VW)
+            const int ew = g.Wo - (int)wo0;
+            const uint32_t lo = ew >= VW ? ones : ((1u << ew) - 1u), hi = ones & ~lo;
+#pragma unroll
+            for (int q = 0; q < NBU; q++) {
+                constexpr int dummy = 0; (void)dummy;
+                const int col = row0 + RPT * q;
+                const int h = (RPT * q) >> 6;          // compile-time: RPT is 64 (VW 8) or 32 (VW 4)
+                const int r = h ? hf_r[1] : hf_r[0], s = h ? hf_s[1] : hf_s[0];
+                const uint32_t cbase = (h ? hf_c[1] : hf_c[0]) + (uint32_t)(col & 63);
+                uint32_t m;
+                int pix;
+                if (S == 1) {
+                    const uint32_t rm = r == PAD ? ones : r < PAD ? (((int)ho0 >= 1 ? lo : 0u) | hi)
+                                                                   : (((int)ho0 <= g.H - 2 ? lo : 0u) | ((int)ho0 + 1 <= g.H - 2 ? hi : 0u));
+                    const uint32_t cm = s == PAD ? ones : s < PAD ? ones & ~((wo0 == 0 ? 1u : 0u) | (ew < VW ? (1u << ew) : 0u))
+                                                                   : ones & ~((ew - 1 < VW) ? (1u << (ew - 1)) : 0u);
+                    m = KS == 1 ? ones : rm & cm;
+                    pix = (int)pp + (r - PAD) * g.W + (s - PAD);
+                } else {
+                    m = ((r == 0 && ho0 == 0) ? 0u : ones) & ~((s == 0 && wo0 == 0) ? 1u : 0u);
+                    pix = (2 * (int)ho0 - PAD + r) * g.W + 2 * (int)wo0 - PAD + s;
+                }
+                if (m == 0) pix = S == 1 ? (int)pp : (2 * (int)ho0) * g.W + 2 * (int)wo0; // nothing valid: stay on the centre pixel
+                const uint32_t off = (n * (uint32_t)(g.C * g.HW) + cbase * (uint32_t)g.HW + (uint32_t)(pix + BG_BIAS / 2)) * 2u; // >= 0
+                wb[q][0] = bg_ldv<VW>((const char *)Bop - BG_BIAS + off);
+                if (S2W) wb[q][1] = bg_ldv<VW>((const char *)Bop - BG_BIAS + off + VW * 2);
+                wmask[q] = (sel_a && (h ? hf_ok[1] : hf_ok[0])) ? m : 0u;
+            }
+            ld_k0 += BG_BK;
         }
+    };
+    // every other 16-bit element of two consecutive vectors (a stride-2 span) packed into one
+    auto evens = [](const LT a, const LT b) -> LT {
+        LT o;
+        if constexpr (VW == 8) {
+            o[0] = __builtin_amdgcn_perm(a[1], a[0], 0x05040100u); o[1] = __builtin_amdgcn_perm(a[3], a[2], 0x05040100u);
+            o[2] = __builtin_amdgcn_perm(b[1], b[0], 0x05040100u); o[3] = __builtin_amdgcn_perm(b[3], b[2], 0x05040100u);
+        } else {
+            o[0] = __builtin_amdgcn_perm(a[1], a[0], 0x05040100u); o[1] = __builtin_amdgcn_perm(b[1], b[0], 0x05040100u);
+        }
+        return o;
     };
     auto stash = [&](const int buf) {
         unsigned char *as = As + buf * (BM * BG_LDB), *bs = Bs + buf * (128 * BG_LDB);
         if (MODE == BG_WGRAD) {
-            const int kx = tid & 31, row = tid >> 5;
+            if (!VEC) {
+                const int kx = tid & 31, row = tid >> 5;
 #pragma unroll
-            for (int q = 0; q < NAS; q++) *(u16 *)(as + (row + 8 * q) * BG_LDB + kx * 2) = sel_a ? ra[q] : (u16)0;
+                for (int q = 0; q < NAS; q++) *(u16 *)(as + (row + 8 * q) * BG_LDB + kx * 2) = sel_a ? ra[q] : (u16)0;
 #pragma unroll
-            for (int q = 0; q < 16; q++)
-                *(u16 *)(bs + (row + 8 * q) * BG_LDB + kx * 2) = ((sel_b >> (q >> 3)) & 1) ? rb[q] : (u16)0;
-        } else {
-            const int bj = tid & 127, kh = tid >> 7;
-            u32x4 lo, hi;
+                for (int q = 0; q < 16; q++)
+                    *(u16 *)(bs + (row + 8 * q) * BG_LDB + kx * 2) = ((sel_b >> (q >> 3)) & 1) ? rb[q] : (u16)0;
+            } else {
+                const int part = tid % NPU, row0 = tid / NPU;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                lo[q] = sel_b ? ((uint32_t)rb[2 * q] | ((uint32_t)rb[2 * q + 1] << 16)) : 0u;
-                hi[q] = sel_b ? ((uint32_t)rb[8 + 2 * q] | ((uint32_t)rb[8 + 2 * q + 1] << 16)) : 0u;
+                for (int q = 0; q < NAU; q++) {
+                    LT v = wa[q];
+#pragma unroll
+                    for (int j = 0; j < LW; j++) v[j] = sel_a ? v[j] : 0u;
+                    *(LT *)(as + (row0 + RPT * q) * BG_LDB + part * (VW * 2)) = v;
+                }
+#pragma unroll
+                for (int q = 0; q < NBU; q++) {
+                    LT v;
+                    if constexpr (S2W) v = evens(wb[q][0], wb[q][1]); else v = wb[q][0];
+#pragma unroll
+                    for (int j = 0; j < LW; j++) v[j] &= bg_lane_mask(wmask[q] >> (2 * j));
+                    *(LT *)(bs + (row0 + RPT * q) * BG_LDB + part * (VW * 2)) = v;
+                }
             }
-            *(u32x4 *)(bs + bj * BG_LDB + kh * 32) = lo;
-            *(u32x4 *)(bs + bj * BG_LDB + kh * 32 + 16) = hi;
+        } else {
+            if (!VEC) {
+                const int bj = tid & 127, kh = tid >> 7;
+                u32x4 lo, hi;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    lo[q] = sel_b ? ((uint32_t)rb[2 * q] | ((uint32_t)rb[2 * q + 1] << 16)) : 0u;
+                    hi[q] = sel_b ? ((uint32_t)rb[8 + 2 * q] | ((uint32_t)rb[8 + 2 * q + 1] << 16)) : 0u;
+                }
+                *(u32x4 *)(bs + bj * BG_LDB + kh * 32) = lo;
+                *(u32x4 *)(bs + bj * BG_LDB + kh * 32 + 16) = hi;
+            } else {
+                // transpose in registers: (channel c, pixels 2j / 2j+1) x (channel c+1, ...) -> one dword (c, c+1) per pixel
+                const int c2 = tid & 15;
+#pragma unroll
+                for (int u = 0; u < NU; u++) {
+                    LT a, b;
+                    if constexpr (S2F) { a = evens(vb[u][0][0], vb[u][0][1]); b = evens(vb[u][1][0], vb[u][1][1]); }
+                    else { a = vb[u][0][0]; b = vb[u][1][0]; }
+                    unsigned char *dst = bs + (((tid >> 4) + 16 * u) * VW) * BG_LDB + c2 * 4;
+#pragma unroll
+                    for (int j = 0; j < LW; j++) {
+                        const uint32_t p0 = __builtin_amdgcn_perm(b[j], a[j], 0x05040100u), p1 = __builtin_amdgcn_perm(b[j], a[j], 0x07060302u);
+                        *(uint32_t *)(dst + (2 * j) * BG_LDB) = ((vmask[u] >> (2 * j)) & 1u) ? p0 : 0u;
+                        *(uint32_t *)(dst + (2 * j + 1) * BG_LDB) = ((vmask[u] >> (2 * j + 1)) & 1u) ? p1 : 0u;
+                    }
+                }
+            }
 #pragma unroll
             for (int q = 0; q < NA; q++) {
                 const int u = tid + 256 * q;
@@ -477,11 +656,10 @@ __global__ void __launch_bounds__(256) bg_b2f_kernel(const u16 *__restrict__ in,
 }
 
 // ------------------------------------------------------------------------------------------------------------
-enum { BGOP_FWD = 0, BGOP_DGRAD = 1, BGOP_WGRAD = 2 };
 int mi_bgemm_supported(int op, int N, int C, int H, int K, int k, int stride) {
     if (!((k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2)))) return 0;
-    if (H % stride || H / stride < 2) return 0;
-    if ((double)N * C * H * H >= 2147483648.0 || (double)N * K * (H / stride) * (H / stride) >= 2147483648.0) return 0; /* 32-bit byte offsets */
+    if (H % stride || H / stride < 2 || H > 120) return 0;
+    if ((double)N * C * H * H >= 2147480000.0 || (double)N * K * (H / stride) * (H / stride) >= 2147480000.0) return 0; /* 32-bit byte offsets (+ BG_BIAS) */
     if (op == BGOP_FWD) return C % 32 == 0 && K % 64 == 0;
     if (op == BGOP_DGRAD) return K % 32 == 0 && C % 64 == 0;
     return C % 64 == 0 && K % 64 == 0;
@@ -513,24 +691,47 @@ static void bgemm_geometry(BgArgs &g, int N, int C, int H, int K, int stride) {
     g.fdP = make_fastdiv(g.P); g.fdWo = make_fastdiv(g.Wo);
     g.fdCb = make_fastdiv(1);
 }
-template <int MODE, int KS, int S, int WMW>
+template <int MODE, int KS, int S, int WMW, int VW>
 static int bgemm_launch_t(hipStream_t st, dim3 grid, const u16 *A, const u16 *B, void *out, const u16 *addend, const BgArgs &g) {
     constexpr int BM = 64 * WMW;
     constexpr size_t tiles_b = (size_t)2 * (BM + 128) * BG_LDB, ep_b = (size_t)4 * 32 * 64 * 4;
     constexpr size_t lds = tiles_b > ep_b ? tiles_b : ep_b;
-    hipLaunchKernelGGL((bgemm_kernel<MODE, KS, S, WMW>), grid, dim3(256), lds, st, A, B, out, addend, g);
+    hipLaunchKernelGGL((bgemm_kernel<MODE, KS, S, WMW, VW>), grid, dim3(256), lds, st, A, B, out, addend, g);
     return 0;
 }
+template <int MODE, int KS, int S>
+static int bgemm_launch_v(hipStream_t st, dim3 grid, const u16 *A, const u16 *B, void *out, const u16 *addend, const BgArgs &g, int bm, int vw) {
+    if (bm == 128) {
+        if (vw == 8) return bgemm_launch_t<MODE, KS, S, 2, 8>(st, grid, A, B, out, addend, g);
+        if (vw == 4) return bgemm_launch_t<MODE, KS, S, 2, 4>(st, grid, A, B, out, addend, g);
+        return bgemm_launch_t<MODE, KS, S, 2, 1>(st, grid, A, B, out, addend, g);
+    }
+    if (vw == 8) return bgemm_launch_t<MODE, KS, S, 1, 8>(st, grid, A, B, out, addend, g);
+    if (vw == 4) return bgemm_launch_t<MODE, KS, S, 1, 4>(st, grid, A, B, out, addend, g);
+    return bgemm_launch_t<MODE, KS, S, 1, 1>(st, grid, A, B, out, addend, g);
+}
+// vw: pixels per operand load of the STAGING (1 = element-wise); see bgemm_stage_vw
 template <int MODE>
 static int bgemm_launch(hipStream_t st, dim3 grid, const u16 *A, const u16 *B, void *out, const u16 *addend, const BgArgs &g, int k,
-                        int stride, int bm) {
-#define BGL(KS_, S_)                                                                              \
-    if (k == KS_ && stride == S_)                                                                 \
-        return bm == 128 ? bgemm_launch_t<MODE, KS_, S_, 2>(st, grid, A, B, out, addend, g)       \
-                         : bgemm_launch_t<MODE, KS_, S_, 1>(st, grid, A, B, out, addend, g);
-    BGL(1, 1) BGL(3, 1) BGL(3, 2)
-#undef BGL
+                        int stride, int bm, int vw) {
+    if (k == 1 && stride == 1) return bgemm_launch_v<MODE, 1, 1>(st, grid, A, B, out, addend, g, bm, vw);
+    if (k == 3 && stride == 1) return bgemm_launch_v<MODE, 3, 1>(st, grid, A, B, out, addend, g, bm, vw);
+    if (k == 3 && stride == 2) return bgemm_launch_v<MODE, 3, 2>(st, grid, A, B, out, addend, g, bm, vw);
     return -2;
+}
+// Pixels per operand load the staging may use.  The VW pixels of a load must lie in one image (plane size a multiple of VW);
+// where the source is read with stride 2 (forward and wgrad of a stride-2 layer) they must also lie in one output row.
+static int bgemm_stage_vw(int op, int P_out, int Wo, int stride) {
+    static int cap = -1;
+    if (cap < 0) { const char *e = getenv("RESNET_MI_BF16_VW"); cap = e ? atoi(e) : 8; } /* experiments: 1 = element-wise gathers only */
+    const bool strided_src = stride == 2 && op != BGOP_DGRAD;
+    const int lim = strided_src ? Wo : P_out;
+    int vw = lim % 8 == 0 ? 8 : lim % 4 == 0 ? 4 : 1;
+    if (P_out % vw) vw = 1;
+    if (vw > cap) vw = cap >= 4 ? (lim % 4 == 0 && P_out % 4 == 0 ? 4 : 1) : 1;
+    // wgrad derives its per-pixel tap masks in closed form for a span that leaves its output row at most once
+    while (op == BGOP_WGRAD && vw > 1 && Wo < vw) vw = (vw == 8 && P_out % 4 == 0) ? 4 : 1;
+    return vw;
 }
 static int bgemm_fam(int k) { return k == 1 ? MI_FAM_GEMM : MI_FAM_PCONV; }
 static int bgemm_pick_bm(int M, long coltiles) {
@@ -570,7 +771,7 @@ int mi_bgemm_fwd(hipStream_t st, mid_workspace *ws, const u16 *x, const float *w
         if (parts->buf && parts->floats >= (size_t)3 * np * K) { g.bn_part = parts->buf; g.bn_np = np; parts->nparts = np; }
     }
     mi_prof_begin(st, bgemm_fam(k), 2.0 * T * (double)g.ncols * C * K, 2.0 * ((double)N * C * g.HW + (double)g.ncols * K) + 4.0 * T * C * K);
-    const int rc = bgemm_launch<BG_FWD>(st, dim3(g.tiles), A, x, y, nullptr, g, k, stride, bm);
+    const int rc = bgemm_launch<BG_FWD>(st, dim3(g.tiles), A, x, y, nullptr, g, k, stride, bm, bgemm_stage_vw(BGOP_FWD, g.P, g.Wo, stride));
     mi_prof_end(st);
     if (rc) return rc;
     MI_LAUNCH_CHECK("bgemm_kernel<fwd>");
@@ -596,7 +797,8 @@ int mi_bgemm_dgrad(hipStream_t st, mid_workspace *ws, const float *w, const u16 
     g.vw = bgemm_vw(g.HW);
     mi_prof_begin(st, bgemm_fam(k), 2.0 * T * (double)g.ncols * C * K,
                   2.0 * ((double)g.ncols * K + (double)N * C * g.HW * (addend ? 2 : 1)) + 4.0 * T * C * K);
-    const int rc = bgemm_launch<BG_DGRAD>(st, dim3(g.tiles, stride == 2 ? 4 : 1), A, dy, dx, addend, g, k, stride, bm);
+    const int rc = bgemm_launch<BG_DGRAD>(st, dim3(g.tiles, stride == 2 ? 4 : 1), A, dy, dx, addend, g, k, stride, bm,
+                                          bgemm_stage_vw(BGOP_DGRAD, g.P, g.Wo, stride));
     mi_prof_end(st);
     if (rc) return rc;
     MI_LAUNCH_CHECK("bgemm_kernel<dgrad>");
@@ -622,7 +824,8 @@ int mi_bgemm_wgrad(hipStream_t st, mid_workspace *ws, const u16 *x, const u16 *d
     g.klen = mi_cdiv(mi_cdiv(kd, splits), BG_BK) * BG_BK;
     const int used = mi_cdiv(kd, g.klen);
     mi_prof_begin(st, bgemm_fam(k), 2.0 * T * (double)kd * C * K, 2.0 * ((double)N * C * g.HW + (double)kd * K) + 4.0 * T * C * K);
-    const int rc = bgemm_launch<BG_WGRAD>(st, dim3(g.tiles, used), dy, x, ws->part, nullptr, g, k, stride, bm);
+    const int rc = bgemm_launch<BG_WGRAD>(st, dim3(g.tiles, used), dy, x, ws->part, nullptr, g, k, stride, bm,
+                                          bgemm_stage_vw(BGOP_WGRAD, g.P, g.Wo, stride));
     if (rc) { mi_prof_end(st); return rc; }
     const int rr = mi_igemm_wgrad_reduce(st, ws->part, dw, K, C, k, used);
     mi_prof_end(st);

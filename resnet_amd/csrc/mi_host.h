@@ -102,6 +102,7 @@ typedef struct MiCtx {
     float last_ms[5];
 } MiCtx;
 
+#define MI_GUARD 256 /* bytes of slack in front of and behind every tensor the bf16 kernels read (see aalloc, mi_malloc) */
 void *mi_ctx_alloc(MiCtx *c, size_t bytes);
 void mi_params_mark_dirty(void);
 /* buckets the data-parallel path cuts for a network (host-only arithmetic shared with backwards_pass): fills

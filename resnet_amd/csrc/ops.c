@@ -7,8 +7,14 @@
 #include <stdlib.h>
 #include "mi_host.h"
 
-void *mi_malloc(size_t bytes) { return mid_malloc(bytes); }
-void mi_free(void *p) { mid_free(p); }
+/* MI_GUARD bytes of slack on both sides: the bf16 convolution operators read tap-shifted operands with 16-byte loads that may
+ * start a few elements before / end a few elements past a tensor (masked lanes); tensors handed to mi_op_*_bf16 must come
+ * from here */
+void *mi_malloc(size_t bytes) {
+    char *p = (char *)mid_malloc(bytes + 2 * MI_GUARD);
+    return p ? p + MI_GUARD : NULL;
+}
+void mi_free(void *p) { if (p) mid_free((char *)p - MI_GUARD); }
 
 static int finish(int rc) {
     mid_stream_sync(mi_global()->compute);

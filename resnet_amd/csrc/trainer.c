@@ -223,8 +223,13 @@ static Cache_BatchNorm *make_cache(MiCtx *c, int input_size, int feature_size, i
     return k;
 }
 static float *falloc(MiCtx *c, size_t n) { return (float *)mi_ctx_alloc(c, n * sizeof(float)); }
-/* an activation tensor of n elements in the trainer's storage type (the struct fields stay `float *`, resnet.h) */
-static float *aalloc(MiCtx *c, size_t n) { return (float *)mi_ctx_alloc(c, n * (c->dtype == MID_BF16 ? 2 : 4)); }
+/* an activation tensor of n elements in the trainer's storage type (the struct fields stay `float *`, resnet.h).  bf16
+ * tensors get MI_GUARD bytes of slack on both sides: the bf16 convolution reads a tap-shifted operand with 16-byte loads,
+ * which reach up to (W + 1) elements before the first / past the last pixel of a tensor (those lanes are masked to zero) */
+static float *aalloc(MiCtx *c, size_t n) {
+    if (c->dtype != MID_BF16) return (float *)mi_ctx_alloc(c, n * 4);
+    return (float *)((char *)mi_ctx_alloc(c, n * 2 + 2 * MI_GUARD) + MI_GUARD);
+}
 
 /* init_activations, resnet.cu:1057-1113.
  * mode 0: the forward tree.  What it keeps follows c->policy (FAST: raw + BN(+ReLU) output per convolution;

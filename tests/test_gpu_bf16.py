@@ -55,6 +55,8 @@ CONV_SHAPES = [
     (512, 28, 1024, 3, 2, 3),   # 588 columns: ragged last tile
     (64, 8, 64, 3, 1, 4),       # config 1 block
     (128, 8, 128, 3, 2, 4),
+    (128, 4, 128, 3, 1, 4),     # 4x4 planes: a 16-byte load spans two rows
+    (256, 4, 256, 3, 1, 5),
     (64, 56, 64, 1, 1, 2),
     (64, 56, 256, 1, 1, 2),
     (256, 56, 64, 1, 1, 2),
