@@ -4,16 +4,16 @@
 // resnet_cudnn_nchw.cu:1196-1211, TENSOR_OP_MATH_ALLOW_CONVERSION, with the storage made explicit).
 //
 //   forward  Y = W * im2col(X)      M = K, columns (n,ho,wo), reduction (tap, c); A = weights rounded to bf16 and re-laid
-//                                   as k-step tiles [t][c/32][K][32] (one tile = one contiguous run of 16-byte loads)
-//   dgrad    dX = W^T * dY          M = C, reduction (tap, k); S=2: four parity classes (blockIdx.y); A = [t][k/32][C][32]
+//                                   as k-step tiles [t][c/64][K][64] (one tile = one contiguous run of 16-byte loads)
+//   dgrad    dX = W^T * dY          M = C, reduction (tap, k); S=2: four parity classes (blockIdx.y); A = [t][k/64][C][64]
 //   wgrad    dW = dY * im2col(X)^T  M = K, columns (tap, 64-channel block) in pairs, reduction (n,ho,wo) split over
 //                                   blockIdx.y; fp32 partials [split][t][k][c] reduced in a fixed order
 //
 // The MFMA operands want the REDUCTION index contiguous per lane (8 bf16 = one ds_read_b128): LDS images are
-// [row or column][32 reduction elements], pitch 80 bytes (conflict-free ds_read_b128: 16 lanes x 20 dwords cover all 64
+// [row or column][64 reduction elements], pitch 144 bytes (conflict-free ds_read_b128: 16 lanes x 36 dwords cover all 64
 // banks).  In NCHW the channel -- the reduction index of forward and dgrad -- is the STRIDED dimension, so the gathered
-// operand is transposed on the way into LDS: a thread gathers 16 channels of ONE pixel (2-byte loads, coalesced along the
-// pixels of a wave), packs them in registers and writes two 16-byte rows pieces.  wgrad reduces over pixels (contiguous),
+// operand is transposed on the way into LDS: a thread gathers 32 channels of ONE pixel (2-byte loads, coalesced along the
+// pixels of a wave), packs them in registers and writes four 16-byte pieces of the pixel's row.  wgrad reduces over pixels (contiguous),
 // so both its operands are gathered along the reduction and go to LDS element-wise.
 // Epilogue of forward / dgrad: accumulators are transposed through LDS so that a lane owns one output channel and 32
 // consecutive pixels -> 16-byte (8 x bf16) stores, and the forward pass leaves per-tile batch-norm statistics (count, mean,
@@ -33,8 +33,8 @@ typedef unsigned short u16;
 
 enum { BG_FWD = 0, BG_DGRAD = 1, BG_WGRAD = 2 };
 enum { BGOP_FWD = 0, BGOP_DGRAD = 1, BGOP_WGRAD = 2 };
-#define BG_BK 32
-#define BG_LDB 80 /* bytes per LDS row: 32 bf16 + 16 bytes of padding */
+#define BG_BK 64
+#define BG_LDB 144 /* bytes per LDS row: 64 bf16 + 16 bytes of padding (36 dwords: 16 lanes of a ds_read_b128 cover all 64 banks) */
 #define BG_BIAS 256 /* = MI_GUARD (mi_host.h): slack bytes in front of / behind every tensor these kernels read; a tap shift of
                        up to (W + 1) elements must fit: W <= 120 (mi_bgemm_supported) */
 
@@ -76,8 +76,9 @@ template <int VW> __device__ __forceinline__ typename BgVec<VW>::T bg_ldv(const 
     else return *(const u32x2_u *)p;
 }
 
-// VW = pixels per operand load: 1 = the element-wise gathers (any plane size); 8 / 4 = 16- / 8-byte loads along the pixels
-// (plane size a multiple of VW; forward with stride 2: output ROW length a multiple of VW), transposed in registers.
+// VW (wgrad only) = pixels per operand load: 1 = element-wise gathers (any plane size); 8 / 4 = 16- / 8-byte loads along the
+// pixels (plane size a multiple of VW; stride 2: output ROW length a multiple of VW).  Forward and dgrad always gather
+// element-wise along the pixels of a wave (see bgemm_stage_vw for what was measured).
 template <int MODE, int KS, int S, int WMW, int VW>
 __global__ void __launch_bounds__(256)
 bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__restrict__ OutV, const u16 *__restrict__ addend,
@@ -86,22 +87,26 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
     constexpr int TN = WMW == 2 ? 2 : 1;
     constexpr int WNC = 32 * TN;
     constexpr int T = KS * KS, PAD = KS / 2;
-    constexpr int NA = BM / 64;   // fwd/dgrad: 16-byte loads of A per thread and tile
-    constexpr int NAS = BM / 8;   // wgrad, VW == 1: 2-byte loads of A per thread and tile
-    constexpr bool VEC = VW > 1;
+    constexpr int NA = BM / 32;              // fwd/dgrad: 16-byte loads of A per thread and tile (BM x 64 bf16)
+    constexpr int NAS = BM / 4;              // wgrad, VW == 1: 2-byte loads of A per thread and tile
+    constexpr bool VEC = MODE == BG_WGRAD && VW > 1;
+    // forward / dgrad with 16-byte operand loads (VW == 8; the source pixels of 8 consecutive columns are consecutive in memory:
+    // stride-1 forward, every dgrad): a thread loads 8 pixels of 4 ADJACENT channels -- 16 lanes cover 128 pixels of one
+    // channel plane, 256 contiguous bytes -- transposes them in registers (v_perm) and writes 8 bytes (4 channels) per pixel.
+    // Its LDS image has pitch 160 bytes with the 16-byte chunks of a row rotated by (row >> 4): ds_read_b128 stays
+    // conflict-free, the transposing ds_write_b64 are 2-way (tools: the search in DESIGN.md section 7).
+    constexpr bool VB = MODE != BG_WGRAD && VW == 8;
+    constexpr int LDBB = VB ? 160 : BG_LDB;   // pitch of the B image
     typedef typename BgVec<VW>::T LT;
-    constexpr int LW = VW / 2;    // dwords per vector load
-    // fwd / dgrad vector staging: a unit = VW pixels x 2 channels; 16 channel pairs x (128 / VW) pixel groups per tile
-    constexpr int NU = VEC ? 8 / VW : 1;               // units per thread
-    constexpr bool S2F = MODE == BG_FWD && S == 2;     // forward, stride 2: VW output pixels <- every other one of 2 VW input pixels
-    // wgrad vector staging: a unit = VW pixels of one row; 32 / VW units per 32-pixel row
-    constexpr int NPU = VEC ? 32 / VW : 1;
-    constexpr int RPT = 256 / NPU;                     // rows one pass of the 256 threads covers
+    constexpr int LW = VW / 2;               // dwords per vector load
+    // wgrad vector staging: a unit = VW pixels of one row; BG_BK / VW units per 64-pixel row
+    constexpr int NPU = VEC ? BG_BK / VW : 1;
+    constexpr int RPT = 256 / NPU;           // rows one pass of the 256 threads covers
     constexpr int NAU = VEC ? BM / RPT : 1, NBU = VEC ? 128 / RPT : 1;
     constexpr bool S2W = MODE == BG_WGRAD && S == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char bg_smem[];
-    unsigned char *As = bg_smem;                         // [2][BM][80 B]
-    unsigned char *Bs = bg_smem + 2 * BM * BG_LDB;       // [2][128][80 B]
+    unsigned char *As = bg_smem;                         // [2][BM][BG_LDB]
+    unsigned char *Bs = bg_smem + 2 * BM * BG_LDB;       // [2][128][LDBB]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = WMW == 2 ? wave >> 1 : 0, wn = WMW == 2 ? wave & 1 : wave;
@@ -127,13 +132,13 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
     // ---- per-thread staging state (byte offsets; every tensor is < 2^32 bytes: mi_bgemm_supported) ----
     uint32_t b_lane = 0;
     uint32_t mask = 0;
-    uint32_t vb_lane[NU];       // VEC: byte offset of (image, centre pixel of the unit's first column, first channel of the pair)
-    uint64_t vm_lo[NU];         // VEC: validity of the unit's VW pixels, 8 bits per tap, taps 0..7
-    uint32_t vm_hi[NU];         //      tap 8
     int ph = 0, pw = 0, ntaps = 1;
     int ntiles = 0, kend = 0;
     int hf_r[2] = {0, 0}, hf_s[2] = {0, 0}, hf_ok[2] = {0, 0};
     uint32_t hf_c[2] = {0, 0};
+    uint32_t vb_lane = 0;       // VB: byte offset (+ BG_BIAS) of (image, centre pixel of the thread's first column, its first channel)
+    uint64_t vm_lo = 0;         // VB: validity of the thread's 8 pixels, 8 bits per tap, taps 0..7
+    uint32_t vm_hi = 0;         //     tap 8
     if (MODE == BG_FWD || MODE == BG_DGRAD) {
         if (MODE == BG_FWD) { ntaps = T; ntiles = T * (g.C / BG_BK); }
         else if (S == 1) { ntaps = T; ntiles = T * (g.K / BG_BK); }
@@ -176,32 +181,27 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
             }
             return m;
         };
-        if (!VEC) {
+        const uint32_t plane = (uint32_t)(MODE == BG_FWD ? g.HW : g.P);
+        if (!VB) {
             uint32_t centre;
             mask = column(n0 + (tid & 127), centre);
-            b_lane = centre + (uint32_t)(16 * (tid >> 7)) * (uint32_t)(MODE == BG_FWD ? g.HW : g.P) * 2u;
+            b_lane = centre + (uint32_t)(32 * (tid >> 7)) * plane * 2u; // + the first reduction channel of this thread within a tile
         } else {
-            const uint32_t plane = (uint32_t)(MODE == BG_FWD ? g.HW : g.P);
+            const int col0 = n0 + (tid & 15) * 8;
+            uint32_t c0 = 0;
 #pragma unroll
-            for (int u = 0; u < NU; u++) {
-                const int col0 = n0 + ((tid >> 4) + 16 * u) * VW;
-                uint64_t lo = 0;
-                uint32_t hi = 0, c0 = 0;
+            for (int e = 0; e < 8; e++) {
+                uint32_t ce;
+                const uint32_t m = column(col0 + e, ce);
+                if (e == 0) c0 = ce;
 #pragma unroll
-                for (int e = 0; e < VW; e++) {
-                    uint32_t ce;
-                    const uint32_t m = column(col0 + e, ce);
-                    if (e == 0) c0 = ce;
-#pragma unroll
-                    for (int t = 0; t < 8; t++) lo |= (uint64_t)((m >> t) & 1u) << (8 * t + e);
-                    hi |= ((m >> 8) & 1u) << e;
-                }
-                // a group past the last column decodes to the last column for every element: its mask is 0 and its loads stay in bounds
-                // + BG_BIAS: the lane offset stays non-negative when a tap shift points a few pixels in front of the tensor (its
-                // very first pixels: masked lanes inside the allocation's guard bytes); the base pointer is lowered to match
-                vb_lane[u] = c0 + (uint32_t)(2 * (tid & 15)) * plane * 2u + BG_BIAS;
-                vm_lo[u] = lo; vm_hi[u] = hi;
+                for (int t = 0; t < 8; t++) vm_lo |= (uint64_t)((m >> t) & 1u) << (8 * t + e);
+                vm_hi |= ((m >> 8) & 1u) << e;
             }
+            // (a group past the last column decodes to the last column for every pixel: mask 0, loads in bounds)
+            // + BG_BIAS: the unsigned offset stays non-negative when a tap points a few pixels in front of the tensor; the base
+            // pointer is lowered to match
+            vb_lane = c0 + (uint32_t)(4 * (tid >> 4)) * plane * 2u + BG_BIAS;
         }
     } else {
 #pragma unroll
@@ -220,9 +220,9 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
 
     // registers of the tile in flight
     u32x4 ra4[NA];
-    u16 ra[NAS], rb[16];
-    LT vb[NU][2][S2F ? 2 : 1];              // VEC fwd/dgrad: [unit][channel of the pair][first / second half of a stride-2 span]
-    uint32_t vmask[NU];
+    u16 ra[NAS], rb[32];
+    u32x4 vb[4];                            // VB: 8 pixels of 4 adjacent channels
+    uint32_t vmask = 0;
     LT wa[NAU], wb[NBU][S2W ? 2 : 1];       // VEC wgrad
     uint32_t wmask[NBU];
     int sel_a = 1, sel_b = 1;
@@ -263,38 +263,32 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
                 ld_c0 += BG_BK;
                 if (ld_c0 == g.K) { ld_c0 = 0; ld_t++; }
             }
-            if (!VEC) {
+            if (!VB) {
                 const uint32_t fb_lane = b_lane + (uint32_t)(sel_b * shift * 2); // outside: centre pixel, stored as 0
 #pragma unroll
-                for (int q = 0; q < 16; q++) rb[q] = ldg16(fb + (size_t)q * bstride, fb_lane);
+                for (int q = 0; q < 32; q++) rb[q] = ldg16(fb + (size_t)q * bstride, fb_lane);
             } else {
+                vmask = t < 8 ? (uint32_t)(vm_lo >> (8 * t)) & 0xffu : vm_hi;
+                const uint32_t off = vb_lane + (uint32_t)((vmask ? shift : 0) * 2); // no valid pixel at all: stay on the centre
+                // two passes of 4 channels: this thread's channels 4 cq .. 4 cq + 3 and + 64 would be the next tile, so the
+                // 64-channel tile is covered by cq = 0..15 with 4 channels each
 #pragma unroll
-                for (int u = 0; u < NU; u++) {
-                    const uint32_t m = t < 8 ? (uint32_t)(vm_lo[u] >> (8 * t)) & 0xffu : vm_hi[u];
-                    vmask[u] = m;
-                    // no valid pixel at all: stay on the centre (always inside the tensor)
-                    const uint32_t off = vb_lane[u] + (uint32_t)((m ? shift : 0) * 2);
-#pragma unroll
-                    for (int c = 0; c < 2; c++) {
-                        vb[u][c][0] = bg_ldv<VW>(fb - BG_BIAS + (size_t)c * bstride + off);
-                        if (S2F) vb[u][c][1] = bg_ldv<VW>(fb - BG_BIAS + (size_t)c * bstride + off + VW * 2);
-                    }
-                }
+                for (int c = 0; c < 4; c++) vb[c] = bg_ldv<8>(fb - BG_BIAS + (size_t)c * bstride + off);
             }
 #pragma unroll
             for (int q = 0; q < NA; q++) ra4[q] = *(const u32x4 *)(fa + (size_t)(tid + 256 * q) * 16);
         } else if (!VEC) {
-            const int kk = ld_k0 + (tid & 31);
+            const int kk = ld_k0 + (tid & 63);
             sel_a = kk < kend;
             const uint32_t kc = sel_a ? (uint32_t)kk : (uint32_t)kend - 1;
             const uint32_t n = fd_div_ge2(kc, g.fdP);
             const uint32_t pp = kc - n * g.P;
             const uint32_t ho = fd_div_ge2(pp, g.fdWo), wo = pp - ho * g.Wo;
-            const uint32_t row = (uint32_t)tid >> 5;
+            const uint32_t row = (uint32_t)tid >> 6;
             const char *fa = (const char *)(Aop + (size_t)m0 * g.P);
             const uint32_t fa_lane = (n * (uint32_t)(g.K * g.P) + pp + row * g.P) * 2u;
 #pragma unroll
-            for (int q = 0; q < NAS; q++) ra[q] = ldg16(fa + (size_t)(8 * q) * g.P * 2, fa_lane);
+            for (int q = 0; q < NAS; q++) ra[q] = ldg16(fa + (size_t)(4 * q) * g.P * 2, fa_lane);
             sel_b = 0;
 #pragma unroll
             for (int h = 0; h < 2; h++) {
@@ -304,7 +298,7 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
                 const uint32_t fb_lane = (n * (uint32_t)(g.C * g.HW) + pix + (row + hf_c[h]) * g.HW) * 2u;
                 sel_b |= (sel_a & inb & hf_ok[h]) << h;
 #pragma unroll
-                for (int q = 0; q < 8; q++) rb[8 * h + q] = ldg16((const char *)Bop + (size_t)(8 * q) * g.HW * 2, fb_lane);
+                for (int q = 0; q < 16; q++) rb[16 * h + q] = ldg16((const char *)Bop + (size_t)(4 * q) * g.HW * 2, fb_lane);
             }
             ld_k0 += BG_BK;
         } else {
@@ -327,9 +321,8 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
             const uint32_t lo = ew >= VW ? ones : ((1u << ew) - 1u), hi = ones & ~lo;
 #pragma unroll
             for (int q = 0; q < NBU; q++) {
-                constexpr int dummy = 0; (void)dummy;
                 const int col = row0 + RPT * q;
-                const int h = (RPT * q) >> 6;          // compile-time: RPT is 64 (VW 8) or 32 (VW 4)
+                const int h = (RPT * q) >> 6;          // compile-time
                 const int r = h ? hf_r[1] : hf_r[0], s = h ? hf_s[1] : hf_s[0];
                 const uint32_t cbase = (h ? hf_c[1] : hf_c[0]) + (uint32_t)(col & 63);
                 uint32_t m;
@@ -346,7 +339,9 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
                     pix = (2 * (int)ho0 - PAD + r) * g.W + 2 * (int)wo0 - PAD + s;
                 }
                 if (m == 0) pix = S == 1 ? (int)pp : (2 * (int)ho0) * g.W + 2 * (int)wo0; // nothing valid: stay on the centre pixel
-                const uint32_t off = (n * (uint32_t)(g.C * g.HW) + cbase * (uint32_t)g.HW + (uint32_t)(pix + BG_BIAS / 2)) * 2u; // >= 0
+                // + BG_BIAS: the unsigned offset stays non-negative when a tap points a few pixels in front of the tensor (masked
+                // lanes inside the allocation's guard bytes); the base pointer is lowered to match
+                const uint32_t off = (n * (uint32_t)(g.C * g.HW) + cbase * (uint32_t)g.HW + (uint32_t)(pix + BG_BIAS / 2)) * 2u;
                 wb[q][0] = bg_ldv<VW>((const char *)Bop - BG_BIAS + off);
                 if (S2W) wb[q][1] = bg_ldv<VW>((const char *)Bop - BG_BIAS + off + VW * 2);
                 wmask[q] = (sel_a && (h ? hf_ok[1] : hf_ok[0])) ? m : 0u;
@@ -366,15 +361,15 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
         return o;
     };
     auto stash = [&](const int buf) {
-        unsigned char *as = As + buf * (BM * BG_LDB), *bs = Bs + buf * (128 * BG_LDB);
+        unsigned char *as = As + buf * (BM * BG_LDB), *bs = Bs + buf * (128 * LDBB);
         if (MODE == BG_WGRAD) {
             if (!VEC) {
-                const int kx = tid & 31, row = tid >> 5;
+                const int kx = tid & 63, row = tid >> 6;
 #pragma unroll
-                for (int q = 0; q < NAS; q++) *(u16 *)(as + (row + 8 * q) * BG_LDB + kx * 2) = sel_a ? ra[q] : (u16)0;
+                for (int q = 0; q < NAS; q++) *(u16 *)(as + (row + 4 * q) * BG_LDB + kx * 2) = sel_a ? ra[q] : (u16)0;
 #pragma unroll
-                for (int q = 0; q < 16; q++)
-                    *(u16 *)(bs + (row + 8 * q) * BG_LDB + kx * 2) = ((sel_b >> (q >> 3)) & 1) ? rb[q] : (u16)0;
+                for (int q = 0; q < 32; q++)
+                    *(u16 *)(bs + (row + 4 * q) * BG_LDB + kx * 2) = ((sel_b >> (q >> 4)) & 1) ? rb[q] : (u16)0;
             } else {
                 const int part = tid % NPU, row0 = tid / NPU;
 #pragma unroll
@@ -394,37 +389,35 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
                 }
             }
         } else {
-            if (!VEC) {
+            if (!VB) {
+                // transposed on the way in: 32 channels of ONE pixel -> 64 contiguous bytes of the pixel's LDS row
                 const int bj = tid & 127, kh = tid >> 7;
-                u32x4 lo, hi;
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    lo[q] = sel_b ? ((uint32_t)rb[2 * q] | ((uint32_t)rb[2 * q + 1] << 16)) : 0u;
-                    hi[q] = sel_b ? ((uint32_t)rb[8 + 2 * q] | ((uint32_t)rb[8 + 2 * q + 1] << 16)) : 0u;
+                for (int i = 0; i < 4; i++) {
+                    u32x4 v;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) v[q] = sel_b ? ((uint32_t)rb[8 * i + 2 * q] | ((uint32_t)rb[8 * i + 2 * q + 1] << 16)) : 0u;
+                    *(u32x4 *)(bs + bj * LDBB + kh * 64 + 16 * i) = v;
                 }
-                *(u32x4 *)(bs + bj * BG_LDB + kh * 32) = lo;
-                *(u32x4 *)(bs + bj * BG_LDB + kh * 32 + 16) = hi;
             } else {
-                // transpose in registers: (channel c, pixels 2j / 2j+1) x (channel c+1, ...) -> one dword (c, c+1) per pixel
-                const int c2 = tid & 15;
+                // 4 channels x 8 pixels in registers -> per pixel one 8-byte piece (channels 4 cq .. 4 cq + 3) of its LDS row
+                const int g8 = tid & 15, cq = tid >> 4;
 #pragma unroll
-                for (int u = 0; u < NU; u++) {
-                    LT a, b;
-                    if constexpr (S2F) { a = evens(vb[u][0][0], vb[u][0][1]); b = evens(vb[u][1][0], vb[u][1][1]); }
-                    else { a = vb[u][0][0]; b = vb[u][1][0]; }
-                    unsigned char *dst = bs + (((tid >> 4) + 16 * u) * VW) * BG_LDB + c2 * 4;
-#pragma unroll
-                    for (int j = 0; j < LW; j++) {
-                        const uint32_t p0 = __builtin_amdgcn_perm(b[j], a[j], 0x05040100u), p1 = __builtin_amdgcn_perm(b[j], a[j], 0x07060302u);
-                        *(uint32_t *)(dst + (2 * j) * BG_LDB) = ((vmask[u] >> (2 * j)) & 1u) ? p0 : 0u;
-                        *(uint32_t *)(dst + (2 * j + 1) * BG_LDB) = ((vmask[u] >> (2 * j + 1)) & 1u) ? p1 : 0u;
-                    }
+                for (int j = 0; j < 4; j++) {
+                    u32x2 e0 = {__builtin_amdgcn_perm(vb[1][j], vb[0][j], 0x05040100u), __builtin_amdgcn_perm(vb[3][j], vb[2][j], 0x05040100u)};
+                    u32x2 e1 = {__builtin_amdgcn_perm(vb[1][j], vb[0][j], 0x07060302u), __builtin_amdgcn_perm(vb[3][j], vb[2][j], 0x07060302u)};
+                    if (!((vmask >> (2 * j)) & 1u)) { e0[0] = 0u; e0[1] = 0u; }
+                    if (!((vmask >> (2 * j + 1)) & 1u)) { e1[0] = 0u; e1[1] = 0u; }
+                    const int r0 = 8 * g8 + 2 * j, r1 = r0 + 1; // r0 >> 4 == r1 >> 4 == g8 >> 1
+                    const int chunk = ((cq >> 1) + (g8 >> 1)) & 7;
+                    *(u32x2 *)(bs + r0 * LDBB + chunk * 16 + (cq & 1) * 8) = e0;
+                    *(u32x2 *)(bs + r1 * LDBB + chunk * 16 + (cq & 1) * 8) = e1;
                 }
             }
 #pragma unroll
             for (int q = 0; q < NA; q++) {
                 const int u = tid + 256 * q;
-                *(u32x4 *)(as + (u >> 2) * BG_LDB + (u & 3) * 16) = ra4[q];
+                *(u32x4 *)(as + (u >> 3) * BG_LDB + (u & 7) * 16) = ra4[q];
             }
         }
     };
@@ -439,14 +432,19 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
         stash(buf ^ 1); // tile it+1 (held in registers) -> the other buffer; then the registers take tile it+2
         fetch();
         const unsigned char *as = As + buf * (BM * BG_LDB) + (wm * 64 + fr) * BG_LDB + fk * 16;
-        const unsigned char *bs = Bs + buf * (128 * BG_LDB) + (wn * WNC + fr) * BG_LDB + fk * 16;
+        const unsigned char *bs = Bs + buf * (128 * LDBB) + (wn * WNC + fr) * LDBB + (VB ? 0 : fk * 16);
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
+        for (int s = 0; s < BG_BK / 16; s++) {
             bf16x8 av[2], bv[TN];
 #pragma unroll
             for (int i = 0; i < 2; i++) av[i] = *(const bf16x8 *)(as + i * 32 * BG_LDB + s * 32);
 #pragma unroll
-            for (int j = 0; j < TN; j++) bv[j] = *(const bf16x8 *)(bs + j * 32 * BG_LDB + s * 32);
+            for (int j = 0; j < TN; j++) {
+                if (VB) { // chunk (2 s + fk) of the row, rotated by (row >> 4)
+                    const int rot = (wn * WNC + j * 32 + fr) >> 4;
+                    bv[j] = *(const bf16x8 *)(bs + j * 32 * LDBB + ((2 * s + fk + rot) & 7) * 16);
+                } else bv[j] = *(const bf16x8 *)(bs + j * 32 * LDBB + s * 32);
+            }
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -625,8 +623,8 @@ bg_wt_all_kernel(const mid_wt_entry *__restrict__ entries, const int *__restrict
     u16 *fw = (u16 *)E.fwd, *dg = (u16 *)E.dgrad;
     for (int e = threadIdx.x; e < T * 1024; e += 256) {
         const int t = e >> 10, u = (e >> 5) & 31, v = e & 31; // v fastest = contiguous output dim
-        if (fw) fw[((size_t)(t * (E.C / 32) + c0 / 32) * E.K + k0 + u) * 32 + v] = bg_f2bf(tile[u][v * T + t]);
-        if (dg) dg[((size_t)(t * (E.K / 32) + k0 / 32) * E.C + c0 + u) * 32 + v] = bg_f2bf(tile[v][u * T + t]);
+        if (fw) fw[((size_t)(t * (E.C / BG_BK) + c0 / BG_BK) * E.K + k0 + u) * BG_BK + (c0 % BG_BK) + v] = bg_f2bf(tile[u][v * T + t]);
+        if (dg) dg[((size_t)(t * (E.K / BG_BK) + k0 / BG_BK) * E.C + c0 + u) * BG_BK + (k0 % BG_BK) + v] = bg_f2bf(tile[v][u * T + t]);
     }
 }
 // the same for one layer (operator layer / no table): grid (C/32, K/32)
@@ -642,8 +640,8 @@ bg_wt_kernel(const float *__restrict__ w, u16 *__restrict__ fw, u16 *__restrict_
     __syncthreads();
     for (int e = threadIdx.x; e < T * 1024; e += 256) {
         const int t = e >> 10, u = (e >> 5) & 31, v = e & 31;
-        if (fw) fw[((size_t)(t * (C / 32) + c0 / 32) * K + k0 + u) * 32 + v] = bg_f2bf(tile[u][v * T + t]);
-        if (dg) dg[((size_t)(t * (K / 32) + k0 / 32) * C + c0 + u) * 32 + v] = bg_f2bf(tile[v][u * T + t]);
+        if (fw) fw[((size_t)(t * (C / BG_BK) + c0 / BG_BK) * K + k0 + u) * BG_BK + (c0 % BG_BK) + v] = bg_f2bf(tile[u][v * T + t]);
+        if (dg) dg[((size_t)(t * (K / BG_BK) + k0 / BG_BK) * C + c0 + u) * BG_BK + (k0 % BG_BK) + v] = bg_f2bf(tile[v][u * T + t]);
     }
 }
 
@@ -660,11 +658,9 @@ int mi_bgemm_supported(int op, int N, int C, int H, int K, int k, int stride) {
     if (!((k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2)))) return 0;
     if (H % stride || H / stride < 2 || H > 120) return 0;
     if ((double)N * C * H * H >= 2147480000.0 || (double)N * K * (H / stride) * (H / stride) >= 2147480000.0) return 0; /* 32-bit byte offsets (+ BG_BIAS) */
-    if (op == BGOP_FWD) return C % 32 == 0 && K % 64 == 0;
-    if (op == BGOP_DGRAD) return K % 32 == 0 && C % 64 == 0;
-    return C % 64 == 0 && K % 64 == 0;
+    return C % 64 == 0 && K % 64 == 0; /* tiles: 64 rows, 64 reduction elements */
 }
-#define BG_SLOTS 768 /* 256 CUs x 3 resident workgroups (40 KB of LDS, <= 128 VGPRs) */
+#define BG_SLOTS 512 /* 256 CUs x 2 resident workgroups (72 KB of LDS) */
 static int bgemm_wgrad_splits(int N, int C, int H, int K, int k, int stride) {
     const int bm = K % 128 == 0 ? 128 : 64;
     const long nhalf = (long)k * k * (C / 64);
@@ -673,7 +669,7 @@ static int bgemm_wgrad_splits(int N, int C, int H, int K, int k, int stride) {
     int best = 1;
     double best_eff = 0;
     for (int s = 1; s <= 512; s++) {
-        if (s > 1 && ksteps / s < 64) break;
+        if (s > 1 && ksteps / s < 32) break;
         const double waves = (double)tiles * s / BG_SLOTS;
         const double eff = waves / (double)((long)((tiles * s + BG_SLOTS - 1) / BG_SLOTS));
         if (eff > best_eff + 0.02) { best_eff = eff; best = s; }
@@ -694,8 +690,18 @@ static void bgemm_geometry(BgArgs &g, int N, int C, int H, int K, int stride) {
 template <int MODE, int KS, int S, int WMW, int VW>
 static int bgemm_launch_t(hipStream_t st, dim3 grid, const u16 *A, const u16 *B, void *out, const u16 *addend, const BgArgs &g) {
     constexpr int BM = 64 * WMW;
-    constexpr size_t tiles_b = (size_t)2 * (BM + 128) * BG_LDB, ep_b = (size_t)4 * 32 * 64 * 4;
+    constexpr size_t ldbb = (MODE != BG_WGRAD && VW == 8) ? 160 : BG_LDB;
+    constexpr size_t tiles_b = (size_t)2 * (BM * BG_LDB + 128 * ldbb), ep_b = (size_t)4 * 32 * 64 * 4;
     constexpr size_t lds = tiles_b > ep_b ? tiles_b : ep_b;
+    static int attr_set = 0;
+    if (!attr_set) {
+        if (lds > 64 * 1024 &&
+            hipFuncSetAttribute((const void *)bgemm_kernel<MODE, KS, S, WMW, VW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            mi_record_error("bgemm_kernel", "cannot raise the dynamic LDS limit");
+            return -1;
+        }
+        attr_set = 1;
+    }
     hipLaunchKernelGGL((bgemm_kernel<MODE, KS, S, WMW, VW>), grid, dim3(256), lds, st, A, B, out, addend, g);
     return 0;
 }
@@ -731,6 +737,17 @@ static int bgemm_stage_vw(int op, int P_out, int Wo, int stride) {
     if (vw > cap) vw = cap >= 4 ? (lim % 4 == 0 && P_out % 4 == 0 ? 4 : 1) : 1;
     // wgrad derives its per-pixel tap masks in closed form for a span that leaves its output row at most once
     while (op == BGOP_WGRAD && vw > 1 && Wo < vw) vw = (vw == 8 && P_out % 4 == 0) ? 4 : 1;
+    // Measured per layer at N = 256 (tools/bench_ops.py --bf16, RESNET_MI_BF16_VW=1 against 8): the vector staging wins for the
+    // weight gradients of stride-1 layers (dY and x rows read as they lie: 10-25 %), and LOSES for forward / dgrad (a wave's
+    // 64 sixteen-byte pieces then lie in 16 different channel planes -- 64 cache lines per load against 2 for the
+    // element-wise gather along the pixels: 3x3 @56 0.39 ms against 0.17) and for stride-2 sources (twice the bytes loaded)
+    static int all = -1;
+    if (all < 0) { const char *e = getenv("RESNET_MI_BF16_VW_ALL"); all = e ? atoi(e) : 0; }
+    if (op != BGOP_WGRAD) { // the 16-byte form only; its source pixels must be consecutive in memory
+        const bool unit_stride_src = op == BGOP_DGRAD || stride == 1;
+        return (unit_stride_src && P_out % 8 == 0 && cap >= 8) ? 8 : 1;
+    }
+    if (!all && stride != 1) vw = 1;
     return vw;
 }
 static int bgemm_fam(int k) { return k == 1 ? MI_FAM_GEMM : MI_FAM_PCONV; }

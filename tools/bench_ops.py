@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--only", default="fwd,dgrad,wgrad")
     ap.add_argument("--filter", default="")
+    ap.add_argument("--bf16", action="store_true", help="the bf16-activation kernels (x, y, dx as bf16 tensors; weights / dw fp32)")
     args = ap.parse_args()
     L = B.load()
     if L.mi_device_count() < 1:
@@ -58,6 +59,14 @@ def main():
         L.mi_op_fill_uniform(w, nw, 2, -0.1, 0.1)
         L.mi_op_fill_uniform(y, ny, 3, -1.0, 1.0)
         flops = 2.0 * k * k * N * Ho * Ho * Cc * K
+        if args.bf16:
+            if Cc == 3:
+                for p in (x, w, y, dx, dw):
+                    L.mi_free(p)
+                continue
+            xb, yb, dxb = (L.mi_malloc(2 * n) for n in (nx, ny, nx))
+            L.mi_op_convert(x, 0, xb, 1, nx)
+            L.mi_op_convert(y, 0, yb, 1, ny)
         for op in args.only.split(","):
             if op == "dgrad" and Cc == 3:
                 continue
@@ -65,7 +74,14 @@ def main():
             for rep in range(args.reps + 1):
                 if rep == 1:
                     L.mi_prof_reset()
-                if op == "fwd":
+                if args.bf16:
+                    if op == "fwd":
+                        rc = L.mi_op_conv_fwd_bf16(xb, w, yb, N, Cc, H, K, k, s)
+                    elif op == "dgrad":
+                        rc = L.mi_op_conv_dgrad_bf16(w, yb, dxb, N, Cc, H, K, k, s, 0)
+                    else:
+                        rc = L.mi_op_conv_wgrad_bf16(xb, yb, dw, N, Cc, H, K, k, s)
+                elif op == "fwd":
                     rc = L.mi_op_conv_fwd(x, w, y, N, Cc, H, K, k, s)
                 elif op == "dgrad":
                     rc = L.mi_op_conv_dgrad(w, y, dx, N, Cc, H, K, k, s, 0)
@@ -82,7 +98,7 @@ def main():
             ms /= args.reps
             tot[op] += ms * cnt
             print("%-18s %-6s %9.3f %9.1f" % (name, op, ms, flops / ms / 1e9))
-        for p in (x, w, y, dx, dw):
+        for p in (x, w, y, dx, dw) + ((xb, yb, dxb) if args.bf16 else ()):
             L.mi_free(p)
     print("per-step totals (ms, weighted by layer count):", {k_: round(v, 1) for k_, v in tot.items()})
 
