@@ -259,6 +259,11 @@ int mi_dp_get_unique_id(void *out, int bytes);                        /* rank 0 
 int mi_dp_init(Train_ResNet *t, int rank, int world, const void *unique_id, int bytes);
 void mi_dp_set_bucket_bytes(Train_ResNet *t, size_t bytes);
 int mi_dp_world(const Train_ResNet *t);
+/* option, default off (the reference has no cross-replica BN): batch-norm statistics and the (dbeta, dgamma) sums
+ * taken over ALL replicas -- two all-reduces of [C] floats per BN layer in forward, one of [2C] in backward, through a
+ * communicator of its own.  unique_id: a second id from mi_dp_get_unique_id (rank 0), broadcast like the first; call after
+ * mi_dp_init.  NULL turns it off again. */
+int mi_dp_enable_sync_bn(Train_ResNet *t, const void *unique_id, int bytes);
 
 /* per-phase device timing of the last step in ms: [0]=load [1]=forward [2]=backward [3]=update [4]=allreduce wait */
 void mi_trainer_last_timings(Train_ResNet *t, float out_ms[5]);

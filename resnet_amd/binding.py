@@ -143,6 +143,7 @@ PROTOTYPES = {
     "mi_dp_init": (_i, [_T, _i, _i, _vp, _i]),
     "mi_dp_set_bucket_bytes": (None, [_T, _sz]),
     "mi_dp_world": (_i, [_T]),
+    "mi_dp_enable_sync_bn": (_i, [_T, _vp, _i]),
     "mi_trainer_last_timings": (None, [_T, C.POINTER(C.c_float * 5)]),
     "mi_prof_enable": (None, [_i]),
     "mi_prof_reset": (None, []),

@@ -347,6 +347,33 @@ static int ew_blocks(size_t nvec) {
     return (int)b;
 }
 
+// ---- cross-replica ("sync") batch norm, an option the reference does not have (default off) ----
+// Every replica holds the same number of samples per channel, so the merge of the replicas' (mean, biased var) is
+//   mean_g = avg_r mean_r,   var_g = avg_r (var_r + (mean_r - mean_g)^2)
+// -- two all-reduce SUMs of [C] floats per BN layer in forward; backward all-reduces the [2C] sums (dbeta, dgamma) once.
+__global__ void bn_sync_k2(const float *__restrict__ sum_means, float *__restrict__ means, const float *__restrict__ vars,
+                           float *__restrict__ tmp, int C, float inv_world) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mg = sum_means[c] * inv_world, d = means[c] - mg;
+    tmp[c] = vars[c] + d * d;
+    means[c] = mg;
+}
+__global__ void bn_sync_k3(const float *__restrict__ tmp, float *__restrict__ vars, int C, float inv_world) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) vars[c] = tmp[c] * inv_world;
+}
+__global__ void bn_sync_pack(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) { out[c] = a[c]; out[C + c] = b[c]; }
+}
+// the replicas' summed (dbeta, dgamma) are what the dx formula needs; the gradient arena gets sum / world, so that the
+// arena's own all-reduce SUM restores the global value on every replica
+__global__ void bn_sync_unpack(const float *__restrict__ in, float *__restrict__ a, float *__restrict__ b, int C, float inv_world) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) { a[c] = in[c] * inv_world; b[c] = in[C + c] * inv_world; }
+}
+
 // dtype codes of the storage types: MID_F32 / MID_BF16 (mi_device.h).  Supported (x, activation) pairs: (f32, f32) the
 // reference's path, (bf16, bf16) the bf16-activation path, (f32, bf16) its stem (the 7x7 convolution keeps fp32 tensors).
 static int bn_vec(int x_dt, int a_dt, int P) {
@@ -365,8 +392,13 @@ static bool bn_pair_ok(int x_dt, int a_dt) {
     } while (0)
 
 static size_t dt_bytes(int dt) { return dt == MID_BF16 ? 2 : 4; }
+static struct { void *comm; int world, force; float *tmp; size_t tmp_floats; } g_bn_sync;
 
 extern "C" {
+/* comm == NULL turns it off.  force: also run the collectives with a one-rank communicator (self-test). */
+void mid_bn_set_sync(void *comm, int world, float *tmp, size_t tmp_floats, int force) {
+    g_bn_sync.comm = comm; g_bn_sync.world = world; g_bn_sync.tmp = tmp; g_bn_sync.tmp_floats = tmp_floats; g_bn_sync.force = force ? 1 : 0;
+}
 size_t mid_bn_ws_floats(int C) { return (size_t)C * BN_SPLIT_MAX * 3; }
 
 size_t mid_bn_parts_floats(int N, int K, int Ho) { return (size_t)3 * (size_t)mi_cdiv((long)N * Ho * Ho, 128) * 4 * K; }
@@ -444,6 +476,19 @@ int mid_bn_fwd_t(mid_stream s, float *ws, const mid_bn_parts *parts, const void 
         hipLaunchKernelGGL(bn_finalize_kernel, dim3(mi_cdiv(C, 4)), dim3(256), 0, st, ws, G, C, means, vars);
         MI_LAUNCH_CHECK("bn_finalize_kernel");
     }
+    if (g_bn_sync.comm && g_bn_sync.world > 1 - g_bn_sync.force) {
+        // statistics over ALL replicas (equal counts): two small all-reduces on the launch stream, through the sync-BN
+        // communicator (its own: the gradient buckets' collectives run concurrently on the comm stream)
+        const float iw = 1.0f / (float)g_bn_sync.world;
+        float *tmp = g_bn_sync.tmp;
+        if (C > g_bn_sync.tmp_floats / 2) { mi_record_error("sync BN", "scratch too small"); return -3; }
+        (void)hipMemcpyAsync(tmp, means, sizeof(float) * C, hipMemcpyDeviceToDevice, st);
+        if (mid_rccl_allreduce_sum(g_bn_sync.comm, tmp, (size_t)C, (mid_stream)st)) return -1;
+        hipLaunchKernelGGL(bn_sync_k2, dim3(mi_cdiv(C, 256)), dim3(256), 0, st, tmp, means, vars, tmp + C, C, iw);
+        if (mid_rccl_allreduce_sum(g_bn_sync.comm, tmp + C, (size_t)C, (mid_stream)st)) return -1;
+        hipLaunchKernelGGL(bn_sync_k3, dim3(mi_cdiv(C, 256)), dim3(256), 0, st, tmp + C, vars, C, iw);
+        MI_LAUNCH_CHECK("bn_sync");
+    }
     const int rc = bn_fwd_apply(st, x, x_dt, gamma, beta, residual, means, vars, y, a_dt, xhat_out, norm_out, N, C, P, eps, relu);
     mi_prof_end(st);
     return rc;
@@ -495,12 +540,22 @@ static int bn_bwd_impl(hipStream_t st, float *ws, const void *x, int x_dt, const
     MI_LAUNCH_CHECK("bn_bwd_finalize_kernel");
     const size_t total = (size_t)N * C * P;
     const FastDiv fdP = make_fastdiv(P), fdC = make_fastdiv(C);
-    const float inv_m = 1.0f / (float)((size_t)N * P);
+    float inv_m = 1.0f / (float)((size_t)N * P);
+    const float *dg_apply = dgamma, *db_apply = dbeta;
+    const bool sync = g_bn_sync.comm && g_bn_sync.world > 1 - g_bn_sync.force;
+    if (sync) {
+        if (2 * C > g_bn_sync.tmp_floats) { mi_record_error("sync BN", "scratch too small"); return -3; }
+        float *tmp = g_bn_sync.tmp;
+        hipLaunchKernelGGL(bn_sync_pack, dim3(mi_cdiv(C, 256)), dim3(256), 0, st, dgamma, dbeta, tmp, C);
+        if (mid_rccl_allreduce_sum(g_bn_sync.comm, tmp, (size_t)2 * C, (mid_stream)st)) return -1;
+        dg_apply = tmp; db_apply = tmp + C;              // sums over every replica's samples
+        inv_m = 1.0f / ((float)g_bn_sync.world * (float)((size_t)N * P));
+    }
     dim3 g2(ew_blocks(total / vec));
     const void *dy_apply = mask_mode == 3 ? gated_out : dy; // mode 3: the gated dy is already there, no mask needed
 #define BWD_APPLY_M(M_, TX, TA, V)                                                                                             \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<M_, TX, TA, V>), g2, block, 0, st, (const TX *)x, (const TA *)dy_apply, (const TA *)mask_src, \
-                       gamma, beta, means, vars, dgamma, dbeta, (TX *)dx, C, P, fdP, fdC, total, inv_m, eps)
+                       gamma, beta, means, vars, dg_apply, db_apply, (TX *)dx, C, P, fdP, fdC, total, inv_m, eps)
 #define BWD_A0(TX, TA, V) BWD_APPLY_M(0, TX, TA, V)
 #define BWD_A1(TX, TA, V) BWD_APPLY_M(1, TX, TA, V)
 #define BWD_A2(TX, TA, V) BWD_APPLY_M(2, TX, TA, V)
@@ -511,6 +566,7 @@ static int bn_bwd_impl(hipStream_t st, float *ws, const void *x, int x_dt, const
 #undef BWD_A1
 #undef BWD_A2
 #undef BWD_APPLY_M
+    if (sync) hipLaunchKernelGGL(bn_sync_unpack, dim3(mi_cdiv(C, 256)), dim3(256), 0, st, g_bn_sync.tmp, dgamma, dbeta, C, 1.0f / (float)g_bn_sync.world);
     mi_prof_end(st);
     MI_LAUNCH_CHECK("bn_bwd_apply_kernel");
     return 0;

@@ -153,6 +153,8 @@ int mid_bn_bwd_gate(mid_stream s, float *stats_ws, const float *x, const float *
 int mid_bn_fwd_t(mid_stream s, float *stats_ws, const mid_bn_parts *parts, const void *x, int x_dt, const float *gamma,
                  const float *beta, const void *residual, float *means, float *vars, void *y, int a_dt, float *xhat_out,
                  float *norm_out, int N, int C, int P, float eps, int relu);
+/* cross-replica batch-norm statistics through `comm` (an RCCL communicator of its own); NULL = per-replica (the reference) */
+void mid_bn_set_sync(void *comm, int world, float *tmp, size_t tmp_floats, int force);
 int mid_bn_stats_t(mid_stream s, float *stats_ws, const void *x, int x_dt, float *means, float *vars, int N, int C, int P);
 int mid_bn_apply_t(mid_stream s, const void *x, int x_dt, const float *gamma, const float *beta, const void *residual,
                    const float *means, const float *vars, void *y, int a_dt, int N, int C, int P, float eps, int relu);

@@ -87,6 +87,8 @@ typedef struct MiCtx {
     mid_event bk_ev[MI_MAX_BUCKETS];
     int n_buckets;
     int sync_bn;                 /* cross-replica batch-norm statistics (default off: the reference has none) */
+    void *sync_bn_comm;          /* its own communicator: BN collectives run on the compute stream, the buckets' on the comm stream */
+    float *sync_bn_tmp;
     /* weight-gradient overlap: wgrad(L) runs on the aux stream next to BN'(L-1); joined before the next dgrad */
     int overlap_wgrad, wgrad_pending; /* 0 serial, 1 wgrad next to the following BN' only, 2 free-running (ring of buffers) */
     mid_event ev_bn_done, ev_wgrad_done;

@@ -1028,6 +1028,7 @@ void destroy_trainer(Train_ResNet *t) {
     mid_device_sync();
     const Dims *d = t->model->dims;
     if (c->comm) mid_rccl_comm_destroy(c->comm);
+    if (c->sync_bn_comm) { mid_bn_set_sync(NULL, 1, NULL, 0, 0); mid_rccl_comm_destroy(c->sync_bn_comm); mid_free(c->sync_bn_tmp); }
     for (int i = 0; i < c->n_allocs; i++) mid_free(c->allocs[i]);
     free(c->allocs); free(c->alloc_bytes);
     for (int i = 0; i < MI_MAX_BUCKETS; i++) mid_event_destroy(c->bk_ev[i]);
@@ -1067,6 +1068,22 @@ int mi_dp_init(Train_ResNet *t, int rank, int world, const void *unique_id, int 
     return 0;
 }
 void mi_dp_set_bucket_bytes(Train_ResNet *t, size_t bytes) { ctx_of(t)->bucket_bytes = bytes; }
+/* Cross-replica batch norm ("offer sync-BN as an option, default off" -- the reference has none): statistics and
+ * the (dbeta, dgamma) sums of every BN layer are all-reduced over the replicas, through a communicator of its own (the
+ * gradient buckets' collectives run concurrently on the comm stream).  unique_id: a SECOND id from mi_dp_get_unique_id,
+ * broadcast like the first.  With it, DP-N equals one replica at batch N x 256 up to summation order. */
+int mi_dp_enable_sync_bn(Train_ResNet *t, const void *unique_id, int bytes) {
+    MiCtx *c = ctx_of(t);
+    if (!unique_id) { mid_bn_set_sync(NULL, 1, NULL, 0, 0); return 0; }
+    if (c->sync_bn_comm) return 0;
+    c->sync_bn_comm = mid_rccl_comm_init(c->rank, c->world, unique_id, bytes);
+    if (!c->sync_bn_comm) return -1;
+    const size_t nf = 2 * 4096;
+    c->sync_bn_tmp = (float *)mid_malloc(nf * sizeof(float));
+    mid_bn_set_sync(c->sync_bn_comm, c->world, c->sync_bn_tmp, nf, 1);
+    c->sync_bn = 1;
+    return 0;
+}
 int mi_dp_world(const Train_ResNet *t) { return ((MiCtx *)t->backend_ctx)->world; }
 
 /* host-only view of the bucket plan (no GPU touched): the cuts backwards_pass will make for this network */

@@ -191,3 +191,43 @@ def test_two_ranks_over_rccl(oracle, tmp_path):
     finally:
         for net in nets:
             net.close()
+
+
+def test_sync_bn_option_one_rank_is_the_identity():
+    """mi_dp_enable_sync_bn (an option the reference does not have; default off): with a one-rank communicator the per-layer
+    all-reduces of (mean), (var + (mean - mean_g)^2) and (dgamma, dbeta) run for real and must change nothing -- same
+    predictions, gradients and parameters bit for bit.  The merge itself (equal counts per replica:
+    mean_g = avg mean_r, var_g = avg (var_r + (mean_r - mean_g)^2)) is checked against whole-batch statistics in numpy."""
+    rng = np.random.RandomState(3)
+    x = rng.randn(2, 64, 5).astype(np.float64) * 2 + 0.7  # 2 replicas x 64 samples x 5 channels
+    mr, vr = x.mean(axis=1), x.var(axis=1)
+    mg = mr.mean(axis=0)
+    vg = (vr + (mr - mg) ** 2).mean(axis=0)
+    assert np.allclose(mg, x.reshape(-1, 5).mean(axis=0)) and np.allclose(vg, x.reshape(-1, 5).var(axis=0))
+    dims, batch = synth.C1S_DIMS, 4
+    params = synth.make_params(dims, perturb_bn=True)
+    im, lab = synth.make_batch(dims, batch, step=0)
+    res = []
+    for sync in (False, True):
+        tr = _trainer(dims, batch, params)
+        try:
+            if sync:
+                nbytes = tr.L.mi_dp_unique_id_bytes()
+                ids = [(C.c_char * nbytes)() for _ in range(2)]
+                for u in ids:
+                    assert tr.L.mi_dp_get_unique_id(u, nbytes) == 0, tr.error()
+                assert tr.L.mi_dp_init(tr.t, 0, 1, ids[0], nbytes) == 0, tr.error()
+                assert tr.L.mi_dp_enable_sync_bn(tr.t, ids[1], nbytes) == 0, tr.error()
+            tr.fill_host_batch(im, lab); tr.load_new_batch(); tr.forward(); tr.backward(); tr.check()
+            tr.L.mi_device_synchronize()
+            grads = [tr.get("grads", i) for i in range(tr.n_locations)]
+            tr.update()
+            assert tr.check_errors() == 0
+            res.append((tr.pred(), grads, [tr.get("params", i) for i in range(tr.n_locations)]))
+        finally:
+            if sync:
+                tr.L.mi_dp_enable_sync_bn(tr.t, None, 0)
+            tr.close()
+    assert np.array_equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1] + res[0][2], res[1][1] + res[1][2]):
+        assert np.array_equal(a, b)
