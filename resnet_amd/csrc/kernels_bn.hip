@@ -401,7 +401,8 @@ void mid_bn_set_sync(void *comm, int world, float *tmp, size_t tmp_floats, int f
 }
 size_t mid_bn_ws_floats(int C) { return (size_t)C * BN_SPLIT_MAX * 3; }
 
-size_t mid_bn_parts_floats(int N, int K, int Ho) { return (size_t)3 * (size_t)mi_cdiv((long)N * Ho * Ho, 128) * 4 * K; }
+/* (the bf16 kernels pad every image's columns to a multiple of 8) */
+size_t mid_bn_parts_floats(int N, int K, int Ho) { return (size_t)3 * (size_t)mi_cdiv((long)N * ((Ho * Ho + 7) / 8 * 8), 128) * 4 * K; }
 
 static int bn_fwd_apply(hipStream_t st, const void *x, int x_dt, const float *gamma, const float *beta, const void *residual,
                         const float *means, const float *vars, void *y, int a_dt, float *xhat_out, float *norm_out, int N, int C,

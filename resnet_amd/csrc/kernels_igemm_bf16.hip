@@ -34,6 +34,9 @@ typedef unsigned short u16;
 enum { BG_FWD = 0, BG_DGRAD = 1, BG_WGRAD = 2 };
 enum { BGOP_FWD = 0, BGOP_DGRAD = 1, BGOP_WGRAD = 2 };
 #define BG_BK 64
+#ifndef BG_ABLATE
+#define BG_ABLATE 0 /* experiments only (tools/variant.sh): 1 = no B loads in the loop, 2 = no loads, 3 = no loads + no LDS stores, 4 = no MFMA */
+#endif
 #define BG_LDB 144 /* bytes per LDS row: 64 bf16 + 16 bytes of padding (36 dwords: 16 lanes of a ds_read_b128 cover all 64 banks) */
 #define BG_BIAS 256 /* = MI_GUARD (mi_host.h): slack bytes in front of / behind every tensor these kernels read; a tap shift of
                        up to (W + 1) elements must fit: W <= 120 (mi_bgemm_supported) */
@@ -41,7 +44,9 @@ enum { BGOP_FWD = 0, BGOP_DGRAD = 1, BGOP_WGRAD = 2 };
 struct BgArgs {
     int N, C, K, H, W, Ho, Wo; // KS x KS, stride S, pad KS/2
     int HW, P;
-    int ncols;                 // fwd/dgrad: N*P columns
+    int ncols;                 // fwd/dgrad: N*Pc columns
+    int Pc;                    // fwd/dgrad: columns per image: P, or P rounded up to 8 for the 16-byte staging (columns >= P of an image: masked)
+    FastDiv fdPc;
     int mtiles, tiles;
     int nhalf, cb64;           // wgrad: 64-column halves = T * C/64; C/64
     int klen;                  // wgrad: reduction length per split (multiple of 32)
@@ -150,10 +155,11 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
         }
         // validity of column j's tap t (bit t), and the byte offset of its centre pixel in channel 0 of its image
         auto column = [&](int j, uint32_t &centre) -> uint32_t {
-            const bool jin = j < g.ncols;
-            const uint32_t jc = jin ? (uint32_t)j : (uint32_t)g.ncols - 1;
-            const uint32_t n = fd_div(jc, g.fdP);
-            const uint32_t p = jc - n * g.P;
+            const uint32_t jc = j < g.ncols ? (uint32_t)j : (uint32_t)g.ncols - 1;
+            const uint32_t n = fd_div(jc, g.fdPc);
+            const uint32_t q = jc - n * g.Pc;
+            const bool jin = j < g.ncols && q < (uint32_t)g.P; // (padding columns of an image: no output pixel)
+            const uint32_t p = min(q, (uint32_t)g.P - 1);
             const uint32_t ho = fd_div(p, g.fdWo), wo = p - ho * g.Wo;
             uint32_t m = 0;
             if (MODE == BG_FWD) {
@@ -230,6 +236,7 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
     int ld_k0 = (MODE == BG_WGRAD) ? (int)blockIdx.y * g.klen : 0;
     auto ldg16 = [](const char *ubase, uint32_t lane_off) -> u16 { return *(const u16 *)(ubase + lane_off); };
 
+    bool abl_started = false;
     auto fetch = [&]() {
         if (MODE == BG_FWD || MODE == BG_DGRAD) {
             const int t = min(ld_t, ntaps - 1); // the two drain iterations re-read the last tap
@@ -263,7 +270,8 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
                 ld_c0 += BG_BK;
                 if (ld_c0 == g.K) { ld_c0 = 0; ld_t++; }
             }
-            if (!VB) {
+            if (BG_ABLATE >= 1 && BG_ABLATE <= 3 && abl_started) { /* keep the registers of the first tiles */ }
+            else if (!VB) {
                 const uint32_t fb_lane = b_lane + (uint32_t)(sel_b * shift * 2); // outside: centre pixel, stored as 0
 #pragma unroll
                 for (int q = 0; q < 32; q++) rb[q] = ldg16(fb + (size_t)q * bstride, fb_lane);
@@ -275,8 +283,10 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
 #pragma unroll
                 for (int c = 0; c < 4; c++) vb[c] = bg_ldv<8>(fb - BG_BIAS + (size_t)c * bstride + off);
             }
+            if (!(BG_ABLATE >= 2 && BG_ABLATE <= 3 && abl_started)) {
 #pragma unroll
-            for (int q = 0; q < NA; q++) ra4[q] = *(const u32x4 *)(fa + (size_t)(tid + 256 * q) * 16);
+                for (int q = 0; q < NA; q++) ra4[q] = *(const u32x4 *)(fa + (size_t)(tid + 256 * q) * 16);
+            }
         } else if (!VEC) {
             const int kk = ld_k0 + (tid & 63);
             sel_a = kk < kend;
@@ -426,10 +436,11 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
     fetch();
     stash(0);
     fetch();
+    abl_started = true;
     __syncthreads();
     for (int it = 0; it < ntiles; it++) {
         const int buf = it & 1;
-        stash(buf ^ 1); // tile it+1 (held in registers) -> the other buffer; then the registers take tile it+2
+        if (!(BG_ABLATE == 3)) stash(buf ^ 1); // tile it+1 (held in registers) -> the other buffer; then the registers take tile it+2
         fetch();
         const unsigned char *as = As + buf * (BM * BG_LDB) + (wm * 64 + fr) * BG_LDB + fk * 16;
         const unsigned char *bs = Bs + buf * (128 * LDBB) + (wn * WNC + fr) * LDBB + (VB ? 0 : fk * 16);
@@ -445,10 +456,17 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
                     bv[j] = *(const bf16x8 *)(bs + j * 32 * LDBB + ((2 * s + fk + rot) & 7) * 16);
                 } else bv[j] = *(const bf16x8 *)(bs + j * 32 * LDBB + s * 32);
             }
+            if (BG_ABLATE == 4) { // keep the fragment reads alive without the matrix pipe
 #pragma unroll
-            for (int i = 0; i < 2; i++)
+                for (int i = 0; i < 2; i++) asm volatile("" ::"v"(av[i]));
 #pragma unroll
-                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; j++) asm volatile("" ::"v"(bv[j]));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
@@ -484,7 +502,7 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
         float *tw = (float *)bg_smem + wave * (32 * 64);
         const int l31 = lane & 31, row = lane;
         const int rowg = m0 + wm * 64 + row;
-        const int nvw = min(WNC, max(0, g.ncols - (n0 + wn * WNC)));
+        int nvw = 0;              // valid columns of this wave (padding columns of an image and columns past the end excluded)
         float s0 = 0.f, sd = 0.f, sq = 0.f;
 #pragma unroll
         for (int j = 0; j < TN; j++) {
@@ -501,12 +519,21 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
             for (int c = 0; c < 32; c++) v[c] = tw[c * 64 + ((((row >> 2) ^ (c & 15))) << 2) + (row & 3)];
             if (stats) {
                 if (j == 0) s0 = v[0];
-                const int nvj = min(32, max(0, nvw - 32 * j));
 #pragma unroll
-                for (int c = 0; c < 32; c++) {
-                    const float d = c < nvj ? v[c] - s0 : 0.f;
-                    sd += d;
-                    sq = fmaf(d, d, sq);
+                for (int gq = 0; gq < 4; gq++) { // the valid columns of an 8-column group are a prefix of it
+                    const int col = n0 + wn * WNC + j * 32 + 8 * gq;
+                    int cnt = 0;
+                    if (col < g.ncols) {
+                        const uint32_t nn = fd_div((uint32_t)col, g.fdPc);
+                        cnt = min(8, max(0, g.P - (int)((uint32_t)col - nn * g.Pc)));
+                    }
+                    nvw += cnt;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const float d = e < cnt ? v[8 * gq + e] - s0 : 0.f;
+                        sd += d;
+                        sq = fmaf(d, d, sq);
+                    }
                 }
             }
             if (wide) {
@@ -515,9 +542,9 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
 #pragma unroll
                     for (int gq = 0; gq < 4; gq++) {
                         const int col = colb + 8 * gq;
-                        if (col < g.ncols) {
-                            const uint32_t n = fd_div((uint32_t)col, g.fdP);
-                            const uint32_t p = (uint32_t)col - n * g.P;
+                        if (col < g.ncols) { // vw == 8: the plane is a multiple of 8, no padding columns
+                            const uint32_t n = fd_div((uint32_t)col, g.fdPc);
+                            const uint32_t p = (uint32_t)col - n * g.Pc;
                             const size_t o = ((size_t)n * Mdim + rowg) * Pout + p;
                             float w8[8];
 #pragma unroll
@@ -540,9 +567,9 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
 #pragma unroll
                     for (int gq = 0; gq < 8; gq++) {
                         const int col = colb + 4 * gq;
-                        if (col < g.ncols) {
-                            const uint32_t n = fd_div((uint32_t)col, g.fdP);
-                            const uint32_t p = (uint32_t)col - n * g.P;
+                        const uint32_t n = fd_div((uint32_t)min(col, g.ncols - 1), g.fdPc);
+                        const uint32_t p = (uint32_t)min(col, g.ncols - 1) - n * g.Pc;
+                        if (col < g.ncols && p < (uint32_t)g.P) { // groups of 4 are whole: the plane is a multiple of 4
                             const size_t o = ((size_t)n * Mdim + rowg) * Pout + p;
                             float w4[4];
 #pragma unroll
@@ -578,8 +605,9 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
         for (int j = 0; j < TN; j++) {
             const int col = n0 + wn * WNC + j * 32 + (lane & 31);
             if (col >= g.ncols) continue;
-            const uint32_t n = fd_div((uint32_t)col, g.fdP);
-            const uint32_t p = (uint32_t)col - n * g.P;
+            const uint32_t n = fd_div((uint32_t)col, g.fdPc);
+            const uint32_t p = (uint32_t)col - n * g.Pc;
+            if (p >= (uint32_t)g.P) continue; // padding column
             size_t coff;
             if (MODE == BG_FWD) coff = (size_t)n * g.K * g.P + p;
             else if (S == 1) coff = (size_t)n * g.C * g.HW + p;
@@ -683,8 +711,8 @@ size_t mi_bgemm_part_floats(int N, int C, int H, int K, int k, int stride) {
 static void bgemm_geometry(BgArgs &g, int N, int C, int H, int K, int stride) {
     g.N = N; g.C = C; g.K = K; g.H = H; g.W = H; g.Ho = H / stride; g.Wo = H / stride;
     g.HW = H * H; g.P = g.Ho * g.Wo;
-    g.ncols = N * g.P;
-    g.fdP = make_fastdiv(g.P); g.fdWo = make_fastdiv(g.Wo);
+    g.Pc = g.P; g.ncols = N * g.P;
+    g.fdP = make_fastdiv(g.P); g.fdWo = make_fastdiv(g.Wo); g.fdPc = g.fdP;
     g.fdCb = make_fastdiv(1);
 }
 template <int MODE, int KS, int S, int WMW, int VW>
@@ -745,7 +773,7 @@ static int bgemm_stage_vw(int op, int P_out, int Wo, int stride) {
     if (all < 0) { const char *e = getenv("RESNET_MI_BF16_VW_ALL"); all = e ? atoi(e) : 0; }
     if (op != BGOP_WGRAD) { // the 16-byte form only; its source pixels must be consecutive in memory
         const bool unit_stride_src = op == BGOP_DGRAD || stride == 1;
-        return (unit_stride_src && P_out % 8 == 0 && cap >= 8) ? 8 : 1;
+        return (unit_stride_src && cap >= 8) ? 8 : 1; /* any plane size: the column space is padded to groups of 8 per image */
     }
     if (!all && stride != 1) vw = 1;
     return vw;
@@ -776,6 +804,8 @@ int mi_bgemm_fwd(hipStream_t st, mid_workspace *ws, const u16 *x, const float *w
     }
     BgArgs g = {};
     bgemm_geometry(g, N, C, H, K, stride);
+    const int svw = bgemm_stage_vw(BGOP_FWD, g.P, g.Wo, stride);
+    if (svw == 8) { g.Pc = (g.P + 7) / 8 * 8; g.ncols = N * g.Pc; g.fdPc = make_fastdiv(g.Pc); }
     const int ctl = mi_cdiv(g.ncols, 128);
     const int bm = bgemm_pick_bm(K, ctl);
     g.mtiles = K / bm;
@@ -787,8 +817,8 @@ int mi_bgemm_fwd(hipStream_t st, mid_workspace *ws, const u16 *x, const float *w
         const int np = ctl * (bm == 128 ? 2 : 4);
         if (parts->buf && parts->floats >= (size_t)3 * np * K) { g.bn_part = parts->buf; g.bn_np = np; parts->nparts = np; }
     }
-    mi_prof_begin(st, bgemm_fam(k), 2.0 * T * (double)g.ncols * C * K, 2.0 * ((double)N * C * g.HW + (double)g.ncols * K) + 4.0 * T * C * K);
-    const int rc = bgemm_launch<BG_FWD>(st, dim3(g.tiles), A, x, y, nullptr, g, k, stride, bm, bgemm_stage_vw(BGOP_FWD, g.P, g.Wo, stride));
+    mi_prof_begin(st, bgemm_fam(k), 2.0 * T * (double)N * g.P * C * K, 2.0 * ((double)N * C * g.HW + (double)N * g.P * K) + 4.0 * T * C * K);
+    const int rc = bgemm_launch<BG_FWD>(st, dim3(g.tiles), A, x, y, nullptr, g, k, stride, bm, svw);
     mi_prof_end(st);
     if (rc) return rc;
     MI_LAUNCH_CHECK("bgemm_kernel<fwd>");
@@ -806,16 +836,17 @@ int mi_bgemm_dgrad(hipStream_t st, mid_workspace *ws, const float *w, const u16 
     }
     BgArgs g = {};
     bgemm_geometry(g, N, C, H, K, stride);
+    const int svw = bgemm_stage_vw(BGOP_DGRAD, g.P, g.Wo, stride);
+    if (svw == 8) { g.Pc = (g.P + 7) / 8 * 8; g.ncols = N * g.Pc; g.fdPc = make_fastdiv(g.Pc); }
     const int ctl = mi_cdiv(g.ncols, 128);
     const int bm = bgemm_pick_bm(C, ctl);
     g.mtiles = C / bm;
     g.tiles = g.mtiles * ctl;
     g.fdM = make_fastdiv(g.mtiles);
     g.vw = bgemm_vw(g.HW);
-    mi_prof_begin(st, bgemm_fam(k), 2.0 * T * (double)g.ncols * C * K,
-                  2.0 * ((double)g.ncols * K + (double)N * C * g.HW * (addend ? 2 : 1)) + 4.0 * T * C * K);
-    const int rc = bgemm_launch<BG_DGRAD>(st, dim3(g.tiles, stride == 2 ? 4 : 1), A, dy, dx, addend, g, k, stride, bm,
-                                          bgemm_stage_vw(BGOP_DGRAD, g.P, g.Wo, stride));
+    mi_prof_begin(st, bgemm_fam(k), 2.0 * T * (double)N * g.P * C * K,
+                  2.0 * ((double)N * g.P * K + (double)N * C * g.HW * (addend ? 2 : 1)) + 4.0 * T * C * K);
+    const int rc = bgemm_launch<BG_DGRAD>(st, dim3(g.tiles, stride == 2 ? 4 : 1), A, dy, dx, addend, g, k, stride, bm, svw);
     mi_prof_end(st);
     if (rc) return rc;
     MI_LAUNCH_CHECK("bgemm_kernel<dgrad>");
