@@ -108,7 +108,7 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
     constexpr int NPU = VEC ? BG_BK / VW : 1;
     constexpr int RPT = 256 / NPU;           // rows one pass of the 256 threads covers
     constexpr int NAU = VEC ? BM / RPT : 1, NBU = VEC ? 128 / RPT : 1;
-    constexpr bool S2W = MODE == BG_WGRAD && S == 2;
+    constexpr bool S2W = false; // (stride-2 weight gradients read the parity planes of x: unit stride, one load)
     extern __shared__ __attribute__((aligned(16))) unsigned char bg_smem[];
     unsigned char *As = bg_smem;                         // [2][BM][BG_LDB]
     unsigned char *Bs = bg_smem + 2 * BM * BG_LDB;       // [2][128][LDBB]
@@ -162,7 +162,14 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
             const uint32_t p = min(q, (uint32_t)g.P - 1);
             const uint32_t ho = fd_div(p, g.fdWo), wo = p - ho * g.Wo;
             uint32_t m = 0;
-            if (MODE == BG_FWD) {
+            if (MODE == BG_FWD && S == 2 && VB) {
+                // x comes as four parity planes per channel (bg_s2d_kernel): [n][c][ph][pw][Ho][Wo].  Tap (r, s) reads plane
+                // ((r + 1) & 1, (s + 1) & 1) at (ho - (r == 0), wo - (s == 0)): unit stride along the output pixels
+                centre = (uint32_t)(n * g.C * g.HW + p) * 2u;
+#pragma unroll
+                for (int t = 0; t < T; t++)
+                    if (jin && (int)ho - (t / KS == 0) >= 0 && (int)wo - (t % KS == 0) >= 0) m |= 1u << t;
+            } else if (MODE == BG_FWD) {
                 centre = (uint32_t)(n * g.C * g.HW + (S * ho) * g.W + S * wo) * 2u;
 #pragma unroll
                 for (int t = 0; t < T; t++) {
@@ -220,7 +227,7 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
             hf_c[h] = hf_ok[h] ? (u - tp * g.cb64) * 64u : 0u;
         }
         const int kbeg = (int)blockIdx.y * g.klen;
-        kend = min(g.N * g.P, kbeg + g.klen);
+        kend = min(g.N * g.Pc, kbeg + g.klen);
         ntiles = (kend - kbeg + BG_BK - 1) / BG_BK;
     }
 
@@ -230,7 +237,7 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
     u32x4 vb[4];                            // VB: 8 pixels of 4 adjacent channels
     uint32_t vmask = 0;
     LT wa[NAU], wb[NBU][S2W ? 2 : 1];       // VEC wgrad
-    uint32_t wmask[NBU];
+    uint32_t wmask[NBU], wamask = 0;
     int sel_a = 1, sel_b = 1;
     int ld_t = 0, ld_c0 = 0;
     int ld_k0 = (MODE == BG_WGRAD) ? (int)blockIdx.y * g.klen : 0;
@@ -248,7 +255,8 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
                 const int r = KS == 3 ? (t * 11) >> 5 : 0, s = t - KS * r;
                 fa = (const char *)(Aop + ((size_t)(t * (g.C / BG_BK) + ld_c0 / BG_BK) * g.K + m0) * BG_BK);
                 fb = (const char *)(Bop + (size_t)ld_c0 * g.HW);
-                shift = (r - PAD) * g.W + (s - PAD);
+                if (S == 2 && VB) shift = (2 * ((r + 1) & 1) + ((s + 1) & 1)) * g.P - (r == 0) * g.Wo - (s == 0); // parity layout
+                else shift = (r - PAD) * g.W + (s - PAD);
                 bstride = (size_t)g.HW * 2;
                 ld_c0 += BG_BK;
                 if (ld_c0 == g.C) { ld_c0 = 0; ld_t++; }
@@ -312,21 +320,25 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
             }
             ld_k0 += BG_BK;
         } else {
-            // VW consecutive pixels of one image per load: dY rows as they lie, x rows shifted by the tap (stride 2: every other
-            // pixel of a 2 VW span); out-of-image pixels are zeroed by per-element masks when the tile goes to LDS
+            // VW consecutive pixels of one image per load: dY rows as they lie, x rows shifted by the tap.  The reduction index
+            // runs over (image, q) with q < Pc = P rounded up to VW: pixels q >= P of an image are masked in BOTH operands.
+            // Stride 2: x comes as four parity planes per channel (bg_s2d_kernel), so every tap is a unit-stride read as well.
             constexpr uint32_t ones = (1u << VW) - 1u;
             const int part = tid % NPU, row0 = tid / NPU;
             const int kk = ld_k0 + part * VW;
             sel_a = kk < kend;
             const uint32_t kc = sel_a ? (uint32_t)kk : (uint32_t)(kend - VW);
-            const uint32_t n = fd_div_ge2(kc, g.fdP);
-            const uint32_t pp = kc - n * g.P;
+            const uint32_t n = fd_div_ge2(kc, g.fdPc);
+            const uint32_t pp = kc - n * g.Pc;                       // < P: a group never starts in the padding
             const uint32_t ho0 = fd_div_ge2(pp, g.fdWo), wo0 = pp - ho0 * g.Wo;
+            const int cntv = min(VW, g.P - (int)pp);
+            const uint32_t inimg = sel_a ? (cntv >= VW ? ones : ((1u << cntv) - 1u)) : 0u;
             const char *fa = (const char *)(Aop + (size_t)m0 * g.P);
             const uint32_t fa_lane = (n * (uint32_t)(g.K * g.P) + pp + (uint32_t)row0 * g.P) * 2u;
 #pragma unroll
-            for (int q = 0; q < NAU; q++) wa[q] = *(const LT *)(fa + (size_t)(RPT * q) * g.P * 2 + fa_lane);
-            // the VW pixels may run over the end of an output row (stride 1 only: stride 2 needs rows of a multiple of VW)
+            for (int q = 0; q < NAU; q++) wa[q] = bg_ldv<VW>(fa + (size_t)(RPT * q) * g.P * 2 + fa_lane);
+            wamask = inimg;
+            // the VW pixels may run over the end of an output row once (VW <= Wo: bgemm_stage_vw)
             const int ew = g.Wo - (int)wo0;
             const uint32_t lo = ew >= VW ? ones : ((1u << ew) - 1u), hi = ones & ~lo;
 #pragma unroll
@@ -335,26 +347,23 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
                 const int h = (RPT * q) >> 6;          // compile-time
                 const int r = h ? hf_r[1] : hf_r[0], s = h ? hf_s[1] : hf_s[0];
                 const uint32_t cbase = (h ? hf_c[1] : hf_c[0]) + (uint32_t)(col & 63);
-                uint32_t m;
+                // taps that look one row up / one column left, one row down / one column right (stride 2: never down / right)
+                const bool up = S == 1 ? r < PAD : r == 0, down = S == 1 && r > PAD;
+                const bool left = S == 1 ? s < PAD : s == 0, right = S == 1 && s > PAD;
+                const uint32_t rm = up ? (((int)ho0 >= 1 ? lo : 0u) | hi)
+                                       : down ? (((int)ho0 <= g.Ho - 2 ? lo : 0u) | ((int)ho0 + 1 <= g.Ho - 2 ? hi : 0u)) : ones;
+                const uint32_t cm = left ? ones & ~((wo0 == 0 ? 1u : 0u) | (ew < VW ? (1u << ew) : 0u))
+                                         : right ? ones & ~((ew - 1 < VW) ? (1u << (ew - 1)) : 0u) : ones;
+                uint32_t m = (KS == 1 ? ones : rm & cm) & inimg;
                 int pix;
-                if (S == 1) {
-                    const uint32_t rm = r == PAD ? ones : r < PAD ? (((int)ho0 >= 1 ? lo : 0u) | hi)
-                                                                   : (((int)ho0 <= g.H - 2 ? lo : 0u) | ((int)ho0 + 1 <= g.H - 2 ? hi : 0u));
-                    const uint32_t cm = s == PAD ? ones : s < PAD ? ones & ~((wo0 == 0 ? 1u : 0u) | (ew < VW ? (1u << ew) : 0u))
-                                                                   : ones & ~((ew - 1 < VW) ? (1u << (ew - 1)) : 0u);
-                    m = KS == 1 ? ones : rm & cm;
-                    pix = (int)pp + (r - PAD) * g.W + (s - PAD);
-                } else {
-                    m = ((r == 0 && ho0 == 0) ? 0u : ones) & ~((s == 0 && wo0 == 0) ? 1u : 0u);
-                    pix = (2 * (int)ho0 - PAD + r) * g.W + 2 * (int)wo0 - PAD + s;
-                }
-                if (m == 0) pix = S == 1 ? (int)pp : (2 * (int)ho0) * g.W + 2 * (int)wo0; // nothing valid: stay on the centre pixel
+                if (S == 1) pix = (int)pp + (r - PAD) * g.W + (s - PAD);
+                else pix = (2 * ((r + 1) & 1) + ((s + 1) & 1)) * g.P + (int)pp - (r == 0) * g.Wo - (s == 0); // parity plane + offset
+                if (m == 0) pix = (int)pp; // nothing valid: stay on a pixel that exists
                 // + BG_BIAS: the unsigned offset stays non-negative when a tap points a few pixels in front of the tensor (masked
                 // lanes inside the allocation's guard bytes); the base pointer is lowered to match
                 const uint32_t off = (n * (uint32_t)(g.C * g.HW) + cbase * (uint32_t)g.HW + (uint32_t)(pix + BG_BIAS / 2)) * 2u;
                 wb[q][0] = bg_ldv<VW>((const char *)Bop - BG_BIAS + off);
-                if (S2W) wb[q][1] = bg_ldv<VW>((const char *)Bop - BG_BIAS + off + VW * 2);
-                wmask[q] = (sel_a && (h ? hf_ok[1] : hf_ok[0])) ? m : 0u;
+                wmask[q] = (h ? hf_ok[1] : hf_ok[0]) ? m : 0u;
             }
             ld_k0 += BG_BK;
         }
@@ -386,7 +395,7 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
                 for (int q = 0; q < NAU; q++) {
                     LT v = wa[q];
 #pragma unroll
-                    for (int j = 0; j < LW; j++) v[j] = sel_a ? v[j] : 0u;
+                    for (int j = 0; j < LW; j++) v[j] &= bg_lane_mask(wamask >> (2 * j));
                     *(LT *)(as + (row0 + RPT * q) * BG_LDB + part * (VW * 2)) = v;
                 }
 #pragma unroll
@@ -673,6 +682,44 @@ bg_wt_kernel(const float *__restrict__ w, u16 *__restrict__ fw, u16 *__restrict_
     }
 }
 
+// x [NC][H][W] -> four parity planes [NC][ph][pw][H/2][W/2] (bf16; H, W even): what the stride-2 forward convolution and its
+// weight gradient read with unit stride.  One thread: two input rows x 8 columns -> 4 output pixels in each of the 4 planes.
+__global__ void __launch_bounds__(256)
+bg_s2d_kernel(const u16 *__restrict__ x, u16 *__restrict__ out, uint32_t units, int H, int W, FastDiv fdUW, FastDiv fdHo) {
+    const int Ho = H / 2, Wo = W / 2, UW = (W + 7) / 8; // units per row pair
+    for (uint32_t u = blockIdx.x * 256u + threadIdx.x; u < units; u += gridDim.x * 256u) {
+        const uint32_t t = fd_div(u, fdUW);
+        const int ux = (int)(u - t * UW);
+        const uint32_t nc = fd_div(t, fdHo);
+        const int a = (int)(t - nc * Ho);
+        const u16 *src = x + (size_t)nc * H * W + (size_t)(2 * a) * W + 8 * ux;
+        u16 *dst = out + (size_t)nc * H * W + (size_t)a * Wo + 4 * ux;
+        const int nv = min(8, W - 8 * ux); // valid columns of this unit (W need not be a multiple of 8)
+#pragma unroll
+        for (int ph = 0; ph < 2; ph++) {
+            if (nv == 8) { // 16 bytes in (any 2-byte alignment), 8 + 8 bytes out
+                const u32x4 v = *(const u32x4_u *)(src + (size_t)ph * W);
+                u32x2 ev = {__builtin_amdgcn_perm(v[1], v[0], 0x05040100u), __builtin_amdgcn_perm(v[3], v[2], 0x05040100u)};
+                u32x2 od = {__builtin_amdgcn_perm(v[1], v[0], 0x07060302u), __builtin_amdgcn_perm(v[3], v[2], 0x07060302u)};
+                *(u32x2_u *)(dst + (size_t)(2 * ph) * Ho * Wo) = ev;
+                *(u32x2_u *)(dst + (size_t)(2 * ph + 1) * Ho * Wo) = od;
+            } else {
+                for (int e = 0; e < nv; e++) dst[(size_t)(2 * ph + (e & 1)) * Ho * Wo + (e >> 1)] = src[(size_t)ph * W + e];
+            }
+        }
+    }
+}
+static int bg_s2d(hipStream_t st, const u16 *x, u16 *out, long NC, int H, int W) {
+    const int UW = (W + 7) / 8, Ho = H / 2;
+    const long units = NC * Ho * UW;
+    if (units >= 2147483648L) { mi_record_error("bg_s2d", "tensor too large"); return -2; }
+    long blocks = (units + 255) / 256;
+    if (blocks > 65536 * 8) blocks = 65536 * 8;
+    hipLaunchKernelGGL(bg_s2d_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, out, (uint32_t)units, H, W, make_fastdiv(UW), make_fastdiv(Ho));
+    MI_LAUNCH_CHECK("bg_s2d_kernel");
+    return 0;
+}
+
 // fp32 <-> bf16 tensors (operator layer, tests)
 __global__ void __launch_bounds__(256) bg_f2b_kernel(const float *__restrict__ in, u16 *__restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = bg_f2bf(in[i]);
@@ -689,6 +736,7 @@ int mi_bgemm_supported(int op, int N, int C, int H, int K, int k, int stride) {
     return C % 64 == 0 && K % 64 == 0; /* tiles: 64 rows, 64 reduction elements */
 }
 #define BG_SLOTS 512 /* 256 CUs x 2 resident workgroups (72 KB of LDS) */
+static int bgemm_wgrad_splits_p(long kd, int C, int K, int k);
 static int bgemm_wgrad_splits(int N, int C, int H, int K, int k, int stride) {
     const int bm = K % 128 == 0 ? 128 : 64;
     const long nhalf = (long)k * k * (C / 64);
@@ -705,7 +753,13 @@ static int bgemm_wgrad_splits(int N, int C, int H, int K, int k, int stride) {
     return best;
 }
 size_t mi_bgemm_part_floats(int N, int C, int H, int K, int k, int stride) {
-    return (size_t)bgemm_wgrad_splits(N, C, H, K, k, stride) * k * k * K * C;
+    const int P = (H / stride) * (H / stride);
+    int mx = 1;
+    for (int vw = 1; vw <= 8; vw *= 2) { // the launch picks its split count on the padded reduction length: take the largest
+        const int s = bgemm_wgrad_splits_p((long)N * ((P + vw - 1) / vw * vw), C, K, k);
+        if (s > mx) mx = s;
+    }
+    return (size_t)mx * k * k * K * C;
 }
 
 static void bgemm_geometry(BgArgs &g, int N, int C, int H, int K, int stride) {
@@ -771,9 +825,9 @@ static int bgemm_stage_vw(int op, int P_out, int Wo, int stride) {
     // element-wise gather along the pixels: 3x3 @56 0.39 ms against 0.17) and for stride-2 sources (twice the bytes loaded)
     static int all = -1;
     if (all < 0) { const char *e = getenv("RESNET_MI_BF16_VW_ALL"); all = e ? atoi(e) : 0; }
-    if (op != BGOP_WGRAD) { // the 16-byte form only; its source pixels must be consecutive in memory
-        const bool unit_stride_src = op == BGOP_DGRAD || stride == 1;
-        return (unit_stride_src && cap >= 8) ? 8 : 1; /* any plane size: the column space is padded to groups of 8 per image */
+    if (op != BGOP_WGRAD) { // the 16-byte form only; its source pixels must be consecutive in memory: every dgrad, forward
+        // with stride 1, and forward with stride 2 once x has been re-laid as parity planes (the caller checks it has the buffer)
+        return cap >= 8 ? 8 : 1; /* any plane size: the column space is padded to groups of 8 per image */
     }
     if (!all && stride != 1) vw = 1;
     return vw;
@@ -804,7 +858,13 @@ int mi_bgemm_fwd(hipStream_t st, mid_workspace *ws, const u16 *x, const float *w
     }
     BgArgs g = {};
     bgemm_geometry(g, N, C, H, K, stride);
-    const int svw = bgemm_stage_vw(BGOP_FWD, g.P, g.Wo, stride);
+    int svw = bgemm_stage_vw(BGOP_FWD, g.P, g.Wo, stride);
+    if (stride == 2 && svw == 8) { // the 16-byte staging reads x as parity planes: one pass over x first
+        if (ws->s2d && ws->s2d_bytes >= (size_t)N * C * g.HW * 2) {
+            if (bg_s2d(st, x, (u16 *)ws->s2d, (long)N * C, H, H)) return -1;
+            x = (const u16 *)ws->s2d;
+        } else svw = 1;
+    }
     if (svw == 8) { g.Pc = (g.P + 7) / 8 * 8; g.ncols = N * g.Pc; g.fdPc = make_fastdiv(g.Pc); }
     const int ctl = mi_cdiv(g.ncols, 128);
     const int bm = bgemm_pick_bm(K, ctl);
@@ -855,12 +915,44 @@ int mi_bgemm_dgrad(hipStream_t st, mid_workspace *ws, const float *w, const u16 
 
 int mi_igemm_wgrad_reduce(hipStream_t st, const float *part, float *dw, int K, int C, int k, int splits); // kernels_igemm.hip
 
+static int bgemm_wgrad_vw(int Wo, int stride, bool have_parity) {
+    static int cap = -1;
+    if (cap < 0) { const char *e = getenv("RESNET_MI_BF16_VW"); cap = e ? atoi(e) : 8; }
+    if (stride == 2 && !have_parity) return 1;
+    // a span of VW output pixels may leave its output row once: VW <= Wo
+    int vw = Wo >= 8 ? 8 : Wo >= 4 ? 4 : 1;
+    if (vw > cap) vw = cap >= 4 && Wo >= 4 ? 4 : 1;
+    return vw;
+}
+static int bgemm_wgrad_splits_p(long kd, int C, int K, int k) {
+    const int bm = K % 128 == 0 ? 128 : 64;
+    const long nhalf = (long)k * k * (C / 64);
+    const long tiles = ((nhalf + 1) / 2) * (K / bm);
+    const long ksteps = (kd + BG_BK - 1) / BG_BK;
+    int best = 1;
+    double best_eff = 0;
+    for (int s = 1; s <= 512; s++) {
+        if (s > 1 && ksteps / s < 32) break;
+        const double waves = (double)tiles * s / BG_SLOTS;
+        const double eff = waves / (double)((long)((tiles * s + BG_SLOTS - 1) / BG_SLOTS));
+        if (eff > best_eff + 0.02) { best_eff = eff; best = s; }
+    }
+    return best;
+}
 int mi_bgemm_wgrad(hipStream_t st, mid_workspace *ws, const u16 *x, const u16 *dy, float *dw, int N, int C, int H, int K, int k, int stride) {
     const int T = k * k;
-    const int splits = bgemm_wgrad_splits(N, C, H, K, k, stride);
-    if (!ws || ws->part_floats < (size_t)splits * T * K * C) { mi_record_error("mi_bgemm_wgrad", "workspace too small"); return -3; }
     BgArgs g = {};
     bgemm_geometry(g, N, C, H, K, stride);
+    const bool parity_ok = stride == 2 && ws && ws->s2d && ws->s2d_bytes >= (size_t)N * C * g.HW * 2;
+    const int vw = bgemm_wgrad_vw(g.Wo, stride, parity_ok);
+    if (vw > 1) { g.Pc = (g.P + vw - 1) / vw * vw; g.fdPc = make_fastdiv(g.Pc); }
+    const long kd = (long)N * g.Pc;
+    const int splits = bgemm_wgrad_splits_p(kd, C, K, k);
+    if (!ws || ws->part_floats < (size_t)splits * T * K * C) { mi_record_error("mi_bgemm_wgrad", "workspace too small"); return -3; }
+    if (stride == 2 && vw > 1) { // x as parity planes: every tap becomes a unit-stride read
+        if (bg_s2d(st, x, (u16 *)ws->s2d, (long)N * C, H, H)) return -1;
+        x = (const u16 *)ws->s2d;
+    }
     const int bm = K % 128 == 0 ? 128 : 64;
     g.mtiles = K / bm;
     g.cb64 = C / 64;
@@ -868,12 +960,10 @@ int mi_bgemm_wgrad(hipStream_t st, mid_workspace *ws, const u16 *x, const u16 *d
     g.fdCb = make_fastdiv(g.cb64);
     g.tiles = g.mtiles * ((g.nhalf + 1) / 2);
     g.fdM = make_fastdiv(g.mtiles);
-    const int kd = N * g.P;
     g.klen = mi_cdiv(mi_cdiv(kd, splits), BG_BK) * BG_BK;
     const int used = mi_cdiv(kd, g.klen);
-    mi_prof_begin(st, bgemm_fam(k), 2.0 * T * (double)kd * C * K, 2.0 * ((double)N * C * g.HW + (double)kd * K) + 4.0 * T * C * K);
-    const int rc = bgemm_launch<BG_WGRAD>(st, dim3(g.tiles, used), dy, x, ws->part, nullptr, g, k, stride, bm,
-                                          bgemm_stage_vw(BGOP_WGRAD, g.P, g.Wo, stride));
+    mi_prof_begin(st, bgemm_fam(k), 2.0 * T * (double)N * g.P * C * K, 2.0 * ((double)N * C * g.HW + (double)N * g.P * K) + 4.0 * T * C * K);
+    const int rc = bgemm_launch<BG_WGRAD>(st, dim3(g.tiles, used), dy, x, ws->part, nullptr, g, k, stride, bm, vw);
     if (rc) { mi_prof_end(st); return rc; }
     const int rr = mi_igemm_wgrad_reduce(st, ws->part, dw, K, C, k, used);
     mi_prof_end(st);

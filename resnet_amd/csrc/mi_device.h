@@ -59,6 +59,10 @@ typedef struct {
     size_t part_floats;
     /* weights of the NEXT call already re-laid by mid_conv_prelayout_all (else NULL: the call re-lays them itself into wt) */
     const float *pre_fwd, *pre_dgrad;
+    /* bf16 path, stride-2 layers: scratch for x re-laid as four parity planes per channel (>= 2 bytes per element of x, with the
+     * guard bytes of every bf16 tensor on both sides); NULL = those layers gather element-wise */
+    void *s2d;
+    size_t s2d_bytes;
 } mid_workspace;
 
 /* One launch that re-lays the weights of many convolutions for the implicit-GEMM kernel: fwd = [t][c][k], dgrad = [t][k][c]

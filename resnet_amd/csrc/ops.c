@@ -24,6 +24,7 @@ static int finish(int rc) {
 static int ws_make(mid_workspace *ws, size_t wt, size_t part) {
     ws->wt_floats = wt; ws->part_floats = part;
     ws->pre_fwd = ws->pre_dgrad = NULL;
+    ws->s2d = NULL; ws->s2d_bytes = 0;
     ws->wt = wt ? (float *)mid_malloc(wt * sizeof(float)) : NULL;
     ws->part = part ? (float *)mid_malloc(part * sizeof(float)) : NULL;
     return (wt && !ws->wt) || (part && !ws->part);
@@ -113,7 +114,10 @@ int mi_op_convert(const void *in, int in_dt, void *out, int out_dt, size_t n) {
 int mi_op_conv_fwd_bf16(const void *x, const float *w, void *y, int N, int C, int H, int K, int k, int stride) {
     mid_workspace ws;
     if (ws_make(&ws, (size_t)k * k * C * K, 0)) return -3;
+    void *par = NULL;
+    if (stride == 2) { ws.s2d_bytes = (size_t)N * C * H * H * 2; par = mi_malloc(ws.s2d_bytes); ws.s2d = par; }
     int rc = finish(mid_conv_fwd_bf16(mi_global()->compute, &ws, x, w, y, N, C, H, K, k, stride, NULL));
+    mi_free(par);
     ws_free(&ws);
     return rc;
 }
@@ -128,7 +132,10 @@ int mi_op_conv_wgrad_bf16(const void *x, const void *dy, float *dw, int N, int C
     mid_workspace ws;
     if (!mid_bf16_supported(2, N, C, H, K, k, stride)) return -2;
     if (ws_make(&ws, 0, mid_bf16_part_floats(N, C, H, K, k, stride))) return -3;
+    void *par = NULL;
+    if (stride == 2) { ws.s2d_bytes = (size_t)N * C * H * H * 2; par = mi_malloc(ws.s2d_bytes); ws.s2d = par; }
     int rc = finish(mid_conv_wgrad_bf16(mi_global()->compute, &ws, x, dy, dw, N, C, H, K, k, stride));
+    mi_free(par);
     ws_free(&ws);
     return rc;
 }

@@ -341,6 +341,18 @@ static void size_workspaces(MiCtx *c, const Dims *d, ConvBlock **blocks, int N) 
         if (b->projection) LAYER(b->incoming_filters, H, b->expanded_depth, b->stride == 2 ? 3 : 1, b->stride);
     }
 #undef LAYER
+    c->ws.s2d = NULL; c->ws.s2d_bytes = 0;
+    if (c->dtype == MID_BF16) { /* parity planes of the largest stride-2 layer's input */
+        size_t mx = 0;
+        for (int i = 0; i < d->n_conv_blocks; i++) {
+            const ConvBlock *b = blocks[i];
+            if (b->stride != 2) continue;
+            const size_t H = b->incoming_spatial_dim, e1 = (size_t)N * b->reduced_depth * H * H, e2 = (size_t)N * b->incoming_filters * H * H;
+            if (e1 > mx) mx = e1;
+            if (b->projection && e2 > mx) mx = e2;
+        }
+        if (mx) { c->ws.s2d_bytes = mx * 2; c->ws.s2d = (char *)mi_ctx_alloc(c, mx * 2 + 2 * MI_GUARD) + MI_GUARD; }
+    }
     c->ws.wt_floats = wt; c->ws.part_floats = part;
     c->ws.wt = wt ? falloc(c, wt) : NULL;
     c->ws.part = part ? falloc(c, part) : NULL;
