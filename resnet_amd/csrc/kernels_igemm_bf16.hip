@@ -683,34 +683,46 @@ bg_wt_kernel(const float *__restrict__ w, u16 *__restrict__ fw, u16 *__restrict_
 }
 
 // x [NC][H][W] -> four parity planes [NC][ph][pw][H/2][W/2] (bf16; H, W even): what the stride-2 forward convolution and its
-// weight gradient read with unit stride.  One thread: two input rows x 8 columns -> 4 output pixels in each of the 4 planes.
+// weight gradient read with unit stride.  One thread: two input rows x 16 columns (two 16-byte loads each, any 2-byte
+// alignment) -> 8 output pixels (one 16-byte store) in each of the 4 planes.
 __global__ void __launch_bounds__(256)
 bg_s2d_kernel(const u16 *__restrict__ x, u16 *__restrict__ out, uint32_t units, int H, int W, FastDiv fdUW, FastDiv fdHo) {
-    const int Ho = H / 2, Wo = W / 2, UW = (W + 7) / 8; // units per row pair
+    const int Ho = H / 2, Wo = W / 2, UW = (W + 15) / 16; // units per row pair
     for (uint32_t u = blockIdx.x * 256u + threadIdx.x; u < units; u += gridDim.x * 256u) {
         const uint32_t t = fd_div(u, fdUW);
         const int ux = (int)(u - t * UW);
         const uint32_t nc = fd_div(t, fdHo);
         const int a = (int)(t - nc * Ho);
-        const u16 *src = x + (size_t)nc * H * W + (size_t)(2 * a) * W + 8 * ux;
-        u16 *dst = out + (size_t)nc * H * W + (size_t)a * Wo + 4 * ux;
-        const int nv = min(8, W - 8 * ux); // valid columns of this unit (W need not be a multiple of 8)
+        const u16 *src = x + (size_t)nc * H * W + (size_t)(2 * a) * W + 16 * ux;
+        u16 *dst = out + (size_t)nc * H * W + (size_t)a * Wo + 8 * ux;
+        const int nv = min(16, W - 16 * ux); // valid columns of this unit (W need not be a multiple of 16)
 #pragma unroll
         for (int ph = 0; ph < 2; ph++) {
-            if (nv == 8) { // 16 bytes in (any 2-byte alignment), 8 + 8 bytes out
-                const u32x4 v = *(const u32x4_u *)(src + (size_t)ph * W);
-                u32x2 ev = {__builtin_amdgcn_perm(v[1], v[0], 0x05040100u), __builtin_amdgcn_perm(v[3], v[2], 0x05040100u)};
-                u32x2 od = {__builtin_amdgcn_perm(v[1], v[0], 0x07060302u), __builtin_amdgcn_perm(v[3], v[2], 0x07060302u)};
-                *(u32x2_u *)(dst + (size_t)(2 * ph) * Ho * Wo) = ev;
-                *(u32x2_u *)(dst + (size_t)(2 * ph + 1) * Ho * Wo) = od;
+            if (nv == 16) {
+                const u32x4 v0 = *(const u32x4_u *)(src + (size_t)ph * W), v1 = *(const u32x4_u *)(src + (size_t)ph * W + 8);
+                u32x4 ev = {__builtin_amdgcn_perm(v0[1], v0[0], 0x05040100u), __builtin_amdgcn_perm(v0[3], v0[2], 0x05040100u),
+                            __builtin_amdgcn_perm(v1[1], v1[0], 0x05040100u), __builtin_amdgcn_perm(v1[3], v1[2], 0x05040100u)};
+                u32x4 od = {__builtin_amdgcn_perm(v0[1], v0[0], 0x07060302u), __builtin_amdgcn_perm(v0[3], v0[2], 0x07060302u),
+                            __builtin_amdgcn_perm(v1[1], v1[0], 0x07060302u), __builtin_amdgcn_perm(v1[3], v1[2], 0x07060302u)};
+                *(u32x4_u *)(dst + (size_t)(2 * ph) * Ho * Wo) = ev;
+                *(u32x4_u *)(dst + (size_t)(2 * ph + 1) * Ho * Wo) = od;
             } else {
-                for (int e = 0; e < nv; e++) dst[(size_t)(2 * ph + (e & 1)) * Ho * Wo + (e >> 1)] = src[(size_t)ph * W + e];
+                int e0 = 0;
+                if (nv >= 8) { // the first 8 columns as one 16-byte load, two 8-byte stores
+                    const u32x4 v = *(const u32x4_u *)(src + (size_t)ph * W);
+                    u32x2 ev = {__builtin_amdgcn_perm(v[1], v[0], 0x05040100u), __builtin_amdgcn_perm(v[3], v[2], 0x05040100u)};
+                    u32x2 od = {__builtin_amdgcn_perm(v[1], v[0], 0x07060302u), __builtin_amdgcn_perm(v[3], v[2], 0x07060302u)};
+                    *(u32x2_u *)(dst + (size_t)(2 * ph) * Ho * Wo) = ev;
+                    *(u32x2_u *)(dst + (size_t)(2 * ph + 1) * Ho * Wo) = od;
+                    e0 = 8;
+                }
+                for (int e = e0; e < nv; e++) dst[(size_t)(2 * ph + (e & 1)) * Ho * Wo + (e >> 1)] = src[(size_t)ph * W + e];
             }
         }
     }
 }
 static int bg_s2d(hipStream_t st, const u16 *x, u16 *out, long NC, int H, int W) {
-    const int UW = (W + 7) / 8, Ho = H / 2;
+    const int UW = (W + 15) / 16, Ho = H / 2;
     const long units = NC * Ho * UW;
     if (units >= 2147483648L) { mi_record_error("bg_s2d", "tensor too large"); return -2; }
     long blocks = (units + 255) / 256;
@@ -950,7 +962,7 @@ int mi_bgemm_wgrad(hipStream_t st, mid_workspace *ws, const u16 *x, const u16 *d
     const int splits = bgemm_wgrad_splits_p(kd, C, K, k);
     if (!ws || ws->part_floats < (size_t)splits * T * K * C) { mi_record_error("mi_bgemm_wgrad", "workspace too small"); return -3; }
     if (stride == 2 && vw > 1) { // x as parity planes: every tap becomes a unit-stride read
-        if (bg_s2d(st, x, (u16 *)ws->s2d, (long)N * C, H, H)) return -1;
+        if (!ws->s2d_valid && bg_s2d(st, x, (u16 *)ws->s2d, (long)N * C, H, H)) return -1;
         x = (const u16 *)ws->s2d;
     }
     const int bm = K % 128 == 0 ? 128 : 64;

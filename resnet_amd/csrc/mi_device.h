@@ -63,6 +63,7 @@ typedef struct {
      * guard bytes of every bf16 tensor on both sides); NULL = those layers gather element-wise */
     void *s2d;
     size_t s2d_bytes;
+    int s2d_valid; /* s2d already holds the parity planes of this call's x (the forward pass of the same layer wrote them) */
 } mid_workspace;
 
 /* One launch that re-lays the weights of many convolutions for the implicit-GEMM kernel: fwd = [t][c][k], dgrad = [t][k][c]

@@ -43,6 +43,7 @@ typedef struct BatchExt {
 BatchExt *mi_batch_ext(Batch *b);
 void mi_batch_ext_free(Batch *b);
 
+typedef struct { void *spatial, *proj; size_t spatial_bytes, proj_bytes; } MiParity; /* parity copies of a striding block's conv inputs */
 typedef struct MiCtx {
     mid_workspace ws;
     float *bn_ws;
@@ -65,6 +66,8 @@ typedef struct MiCtx {
     float *rc_buf[2];            /* RECOMPUTE_BN: scratch for the BN(+ReLU) tensors (forward: consumed at once; backward: re-derived) */
     float *stem_dx;              /* bf16 mode: the stem convolution's output gradient stays fp32 */
     int counting_act;
+    int overlap_set;             /* mi_trainer_set_overlap was called: keep the caller's mode */
+    MiParity *par;               /* bf16: per block, NULL buffers for blocks that do not stride */
     int params_dirty;            /* parameters written from the host since the last weight re-layout */
     char *dump_root;
     /* every device allocation of this trainer (freed by destroy_trainer) */

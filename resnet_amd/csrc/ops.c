@@ -24,7 +24,7 @@ static int finish(int rc) {
 static int ws_make(mid_workspace *ws, size_t wt, size_t part) {
     ws->wt_floats = wt; ws->part_floats = part;
     ws->pre_fwd = ws->pre_dgrad = NULL;
-    ws->s2d = NULL; ws->s2d_bytes = 0;
+    ws->s2d = NULL; ws->s2d_bytes = 0; ws->s2d_valid = 0;
     ws->wt = wt ? (float *)mid_malloc(wt * sizeof(float)) : NULL;
     ws->part = part ? (float *)mid_malloc(part * sizeof(float)) : NULL;
     return (wt && !ws->wt) || (part && !ws->part);

@@ -341,17 +341,20 @@ static void size_workspaces(MiCtx *c, const Dims *d, ConvBlock **blocks, int N) 
         if (b->projection) LAYER(b->incoming_filters, H, b->expanded_depth, b->stride == 2 ? 3 : 1, b->stride);
     }
 #undef LAYER
-    c->ws.s2d = NULL; c->ws.s2d_bytes = 0;
-    if (c->dtype == MID_BF16) { /* parity planes of the largest stride-2 layer's input */
-        size_t mx = 0;
+    c->ws.s2d = NULL; c->ws.s2d_bytes = 0; c->ws.s2d_valid = 0;
+    free(c->par); c->par = NULL;
+    if (c->dtype == MID_BF16) {
+        /* stride-2 layers read their input as four parity planes per channel (kernels_igemm_bf16.hip): one copy per such layer,
+         * written by the forward pass and read again by the weight gradient (1.1 GB in all at N = 256) */
+        c->par = (MiParity *)calloc((size_t)(d->n_conv_blocks > 0 ? d->n_conv_blocks : 1), sizeof(MiParity));
         for (int i = 0; i < d->n_conv_blocks; i++) {
             const ConvBlock *b = blocks[i];
             if (b->stride != 2) continue;
             const size_t H = b->incoming_spatial_dim, e1 = (size_t)N * b->reduced_depth * H * H, e2 = (size_t)N * b->incoming_filters * H * H;
-            if (e1 > mx) mx = e1;
-            if (b->projection && e2 > mx) mx = e2;
+            c->par[i].spatial_bytes = e1 * 2;
+            c->par[i].spatial = (char *)mi_ctx_alloc(c, e1 * 2 + 2 * MI_GUARD) + MI_GUARD;
+            if (b->projection) { c->par[i].proj_bytes = e2 * 2; c->par[i].proj = (char *)mi_ctx_alloc(c, e2 * 2 + 2 * MI_GUARD) + MI_GUARD; }
         }
-        if (mx) { c->ws.s2d_bytes = mx * 2; c->ws.s2d = (char *)mi_ctx_alloc(c, mx * 2 + 2 * MI_GUARD) + MI_GUARD; }
     }
     c->ws.wt_floats = wt; c->ws.part_floats = part;
     c->ws.wt = wt ? falloc(c, wt) : NULL;
@@ -442,7 +445,12 @@ static void build_buffers(Train_ResNet *t) {
     for (int i = 0; i < MI_RING; i++) { c->ring_buf[i] = i < 4 ? pool[2 + i] : aalloc(c, maxe); c->ring_busy[i] = 0; }
     c->ring_next = 0;
     t->backprop_buffer->activation_derivs = build_activations(c, d, blocks, N, pool, c->policy == MI_STORE_FULL ? 2 : 1);
-    if (c->policy != MI_STORE_FAST && c->overlap_wgrad > 1) c->overlap_wgrad = 1; /* ring mode re-points derivative tensors */
+    /* ring mode re-points derivative tensors to equal-sized slots: FAST policy and fp32 only (the bf16 path keeps the stem's
+     * fp32 gradient in a buffer of its own) */
+    if ((c->policy != MI_STORE_FAST || c->dtype != MID_F32) && c->overlap_wgrad > 1) c->overlap_wgrad = 1;
+    /* bf16: the weight gradients are no longer bound by the matrix pipe but by memory, like the batch norm they would run
+     * next to -- measured 6028 img/s serial against 5973 overlapped; an explicit RESNET_MI_OVERLAP still wins */
+    if (c->dtype == MID_BF16 && !getenv("RESNET_MI_OVERLAP") && !c->overlap_set) c->overlap_wgrad = 0;
     size_workspaces(c, d, blocks, N);
     mid_stream_sync(G.compute);
 }
@@ -596,7 +604,8 @@ void mi_trainer_set_overlap(Train_ResNet *t, int mode) {
     MiCtx *c = ctx_of(t);
     mid_stream_sync(G.aux); mid_stream_sync(G.compute);
     c->overlap_wgrad = mode < 0 ? 0 : mode > 2 ? 2 : mode;
-    if (c->policy != MI_STORE_FAST && c->overlap_wgrad > 1) c->overlap_wgrad = 1; /* the ring re-points derivative tensors */
+    c->overlap_set = 1;
+    if ((c->policy != MI_STORE_FAST || c->dtype != MID_F32) && c->overlap_wgrad > 1) c->overlap_wgrad = 1; /* the ring re-points derivative tensors */
     c->wgrad_pending = 0;
     for (int i = 0; i < MI_RING; i++) c->ring_busy[i] = 0;
     if (c->overlap_wgrad != 2) { /* back to the fixed aliasing of build_activations */
@@ -662,10 +671,12 @@ static void poll_nan_flag(Train_ResNet *t) {
 
 /* conv + BN (+ReLU | +residual+ReLU): prepareAndDoConvolution + prepareAndDoBatchNormAndActivate.
  * stem: the 7x7 convolution keeps fp32 input / output in every storage type; only its BN output is an activation tensor */
+static void *g_par; static size_t g_par_bytes; /* parity copy of the NEXT stride-2 convolution's input (set by the caller) */
 static void unit_fwd(Train_ResNet *t, const float *in, const float *w, const BatchNorm *bn, Cache_BatchNorm *cache,
                      float *conv_out, float *act_out, const float *residual, int C, int H, int K, int k, int stride,
                      int relu, int stem) {
     MiCtx *c = ctx_of(t);
+    c->ws.s2d = stride == 2 ? g_par : NULL; c->ws.s2d_bytes = stride == 2 ? g_par_bytes : 0; c->ws.s2d_valid = 0;
     const int N = t->batch_size, Ho = H / stride;
     const int bf = c->dtype == MID_BF16 && !stem;
     /* the convolution leaves per-tile (count, mean, M2) partials of its output: BN reads the tensor twice, not three times */
@@ -700,10 +711,12 @@ void forward_pass(Train_ResNet *t) {
         const int H = b->incoming_spatial_dim, Ho = H / b->stride;
         unit_fwd(t, bin, b->depth_reduction, b->norm_depth_reduction, k->norm_post_reduced, k->post_reduced,
                  k->post_reduced_activated, NULL, b->incoming_filters, H, b->reduced_depth, 1, 1, 1, 0);
+        g_par = c->par ? c->par[i].spatial : NULL; g_par_bytes = c->par ? c->par[i].spatial_bytes : 0;
         unit_fwd(t, k->post_reduced_activated, b->spatial, b->norm_spatial, k->norm_post_spatial, k->post_spatial,
                  k->post_spatial_activated, NULL, b->reduced_depth, H, b->reduced_depth, 3, b->stride, 1, 0);
         const float *res = bin;
         if (b->projection) { /* resnet.cu:1685-1704 */
+            g_par = c->par ? c->par[i].proj : NULL; g_par_bytes = c->par ? c->par[i].proj_bytes : 0;
             unit_fwd(t, bin, b->projection, b->norm_projection, k->norm_post_projection, k->transformed_residual,
                      k->post_projection_norm_vals, NULL, b->incoming_filters, H, b->expanded_depth, b->stride == 2 ? 3 : 1,
                      b->stride, 0, 0);
@@ -775,6 +788,8 @@ static void conv_dgrad_t(Train_ResNet *t, const float *w, const float *dy, float
 static void conv_wgrad_t(Train_ResNet *t, mid_stream st, const float *x, const float *dy, float *dw, int C, int H, int K, int k, int stride,
                          int stem) {
     MiCtx *c = ctx_of(t);
+    /* the forward pass left the parity planes of x in the layer's own buffer: the weight gradient reads them again */
+    c->ws.s2d = stride == 2 ? g_par : NULL; c->ws.s2d_bytes = stride == 2 ? g_par_bytes : 0; c->ws.s2d_valid = stride == 2 && g_par != NULL;
     if (c->dtype == MID_BF16 && !stem) ck(mid_conv_wgrad_bf16(st, &c->ws, x, dy, dw, t->batch_size, C, H, K, k, stride), "convolution wgrad (bf16)");
     else ck(mid_conv_wgrad(st, &c->ws, x, dy, dw, t->batch_size, C, H, K, k, stride), "convolution wgrad");
 }
@@ -857,6 +872,7 @@ void backwards_pass(Train_ResNet *t) {
         if (b->projection) {
             /* ReLU' of the block output (doActivationDeriv, :1934) is fused into the projection BN' as an external mask; that
              * pass also leaves relu'(out) * up in dk->output, which the expansion BN' then reads instead of up + mask */
+            g_par = c->par ? c->par[i].proj : NULL; g_par_bytes = c->par ? c->par[i].proj_bytes : 0;
             unit_bwd(t, bin, b->projection, b->norm_projection, k->norm_post_projection, db->norm_projection,
                      k->transformed_residual, up, k->output_activated, 3, dk->output, dk->transformed_residual, s_proj, dbin, NULL,
                      db->projection, b->incoming_filters, H, b->expanded_depth, b->stride == 2 ? 3 : 1, b->stride, 0);
@@ -881,6 +897,7 @@ void backwards_pass(Train_ResNet *t) {
             ck(mid_bn_apply_t(G.compute, k->post_reduced, c->dtype, b->norm_depth_reduction->gamma, b->norm_depth_reduction->beta, NULL,
                               k->norm_post_reduced->means, k->norm_post_reduced->vars, k->post_reduced_activated, c->dtype, N, b->reduced_depth,
                               H * H, t->eps, 1), "BN recompute");
+        g_par = c->par ? c->par[i].spatial : NULL; g_par_bytes = c->par ? c->par[i].spatial_bytes : 0;
         unit_bwd(t, k->post_reduced_activated, b->spatial, b->norm_spatial, k->norm_post_spatial, db->norm_spatial,
                  k->post_spatial, dk->post_spatial_activated, NULL, 1, NULL, dk->post_spatial, s_spa, dk->post_reduced_activated, NULL,
                  db->spatial, b->reduced_depth, H, b->reduced_depth, 3, b->stride, 0);
@@ -1062,7 +1079,7 @@ void destroy_trainer(Train_ResNet *t) {
     mi_batch_ext_free(t->cur_batch);
     free(t->model->dims); free(t->model);
     free(t->loss_per_epoch); free(t->accuracy_per_epoch);
-    free(c->dump_root); free(c);
+    free(c->dump_root); free(c->par); free(c);
     free(t);
 }
 
