@@ -569,7 +569,8 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
                             u32x4 pk;
 #pragma unroll
                             for (int e = 0; e < 4; e++) pk[e] = bg_pack2(w8[2 * e], w8[2 * e + 1]);
-                            *(u32x4 *)(Out + o) = pk;
+                            if (BG_ABLATE == 5) { if (pk[0] == 0x12345678u) *(u32x4 *)(Out + o) = pk; } /* experiment: no output stores */
+                            else *(u32x4 *)(Out + o) = pk;
                         }
                     }
                 } else { // 4 pixels per store
@@ -847,6 +848,9 @@ static int bgemm_stage_vw(int op, int P_out, int Wo, int stride) {
 static int bgemm_fam(int k) { return k == 1 ? MI_FAM_GEMM : MI_FAM_PCONV; }
 static int bgemm_pick_bm(int M, long coltiles) {
     if (M % 128) return 64;
+    static int force = -1;
+    if (force < 0) { const char *e = getenv("RESNET_MI_BF16_BM"); force = e ? atoi(e) : 0; }
+    if (force == 64 || force == 128) return force;
     // 64-row tiles where 128-row ones would leave most of the chip empty (fewer than one workgroup per CU)
     return (long)(M / 128) * coltiles < 256 ? 64 : 128;
 }

@@ -337,3 +337,30 @@ def test_bf16_halves_the_stored_activations():
             tr.set_store_policy(B.MI_STORE_FULL)
     finally:
         tr.close()
+
+
+def test_overlap_modes_in_bf16_are_bit_identical_and_ring_mode_is_refused():
+    """mode 2 (free-running weight gradients over a ring of equal-sized derivative buffers) exists for fp32 only -- the bf16 path
+    keeps the stem's fp32 gradient in a buffer of its own -- and a request for it falls back to mode 1 (regression: it used
+    to write that gradient into a half-sized ring slot).  Modes 0 and 1 give the same bits."""
+    from resnet_amd import Trainer
+    from resnet_amd import binding as B
+    dims, batch = synth.C1S_DIMS, 4
+    params = synth.make_params(dims, perturb_bn=True)
+    im, lab = synth.make_batch(dims, batch, step=0)
+    out = []
+    for mode in (0, 1, 2):
+        tr = Trainer(dims, batch, **HYPER)
+        try:
+            tr.set_dtype(BF16)
+            tr.L.mi_trainer_set_overlap(tr.t, mode)
+            tr.set_params(params)
+            tr.source_host(B.MI_LAYOUT_NHWC)
+            tr.fill_host_batch(im, lab); tr.load_new_batch(); tr.forward(); tr.backward(); tr.check()
+            tr.L.mi_device_synchronize()
+            out.append([tr.get("grads", i) for i in range(tr.n_locations)])
+        finally:
+            tr.close()
+    for g in out[1:]:
+        for a, b in zip(out[0], g):
+            assert np.array_equal(a, b)
