@@ -58,7 +58,7 @@ def _time_oracle(o, dims, batch, threads):
 
 def cpu_baseline():
     """The oracle (a CPU port: the reference has no CPU path) on bounded samples of the same workload, timed on this
-    host: the reference-defined ResNet-50 at batch 4 on every core the process may use (the headline `value`), config 1
+    host: the reference-defined ResNet-50 at batch 12 on every core the process may use (the headline `value`), config 1
     (BASELINE configs[0]) in full on one thread and on all of them.  A single-thread ResNet-50 step is not run: at the
     per-thread rate measured here it would take over a minute per image."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -76,7 +76,7 @@ def cpu_baseline():
     o = Oracle("f32")
     c1_1 = min(_time_oracle(o, synth.C1_DIMS, synth.C1_BATCH, 1) for _ in range(3))
     c1_n = min(_time_oracle(o, synth.C1_DIMS, synth.C1_BATCH, cores) for _ in range(3))
-    batch = 4
+    batch = 12  # ~13 s on 16 threads: inside the 10-30 s the sample is meant to take
     dt = _time_oracle(o, synth.R50_DIMS, batch, cores)
     return {"value": round(batch / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": "1 full training step (fwd+loss+bwd+Adam) of the reference-defined ResNet-50 fp32 224x224 at batch %d, "
