@@ -58,9 +58,9 @@ def _time_oracle(o, dims, batch, threads):
 
 def cpu_baseline():
     """The oracle (a CPU port: the reference has no CPU path) on bounded samples of the same workload, timed on this
-    host: the reference-defined ResNet-50 at batch 12 on every core the process may use (the headline `value`), config 1
-    (BASELINE configs[0]) in full on one thread and on all of them.  A single-thread ResNet-50 step is not run: at the
-    per-thread rate measured here it would take over a minute per image."""
+    host: the reference-defined ResNet-50 at batch 4 on every core the process may use (the headline `value`), config 1
+    (BASELINE configs[0]) in full on one thread and on all of them.  The single-thread ResNet-50 sample is one image (batch 1):
+    batch 4 on one thread would take about a minute."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import synth
     from oracle.oracle_py import Oracle
@@ -76,15 +76,17 @@ def cpu_baseline():
     o = Oracle("f32")
     c1_1 = min(_time_oracle(o, synth.C1_DIMS, synth.C1_BATCH, 1) for _ in range(3))
     c1_n = min(_time_oracle(o, synth.C1_DIMS, synth.C1_BATCH, cores) for _ in range(3))
-    batch = 12  # ~13 s on 16 threads: inside the 10-30 s the sample is meant to take
+    batch = 4
     dt = _time_oracle(o, synth.R50_DIMS, batch, cores)
+    dt1 = _time_oracle(o, synth.R50_DIMS, 1, 1)  # one image on one thread: the scalar-port rate (~10-20 s)
     return {"value": round(batch / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": "1 full training step (fwd+loss+bwd+Adam) of the reference-defined ResNet-50 fp32 224x224 at batch %d, "
                       "oracle/liboracle_f32.so with %d OpenMP threads (`cores` = threads used; the host shows %d CPUs), %.1f s" % (batch, cores, visible, dt),
             "config1_images_per_sec_1_thread": round(synth.C1_BATCH / c1_1, 2),
             "config1_images_per_sec_all_threads": round(synth.C1_BATCH / c1_n, 2),
             "config1_sample": "config 1 (1 block, batch 4, 32x32): one full step, best of 3, %.1f ms on 1 thread, %.1f ms on %d" % (c1_1 * 1e3, c1_n * 1e3, cores),
-            "resnet50_1_thread": "not run (bounded sample: ~%.0f s per image at the per-thread rate above)" % (dt * cores / batch)}
+            "resnet50_images_per_sec_1_thread": round(1.0 / dt1, 4),
+            "resnet50_1_thread_sample": "the same step at batch 1 on 1 thread, %.1f s" % dt1}
 
 
 def main():
