@@ -20,6 +20,7 @@
 // M2, computed from the fp32 accumulators before rounding) exactly as the fp32 kernel does.
 #include <stdlib.h>
 #include "mi_common.hpp"
+#include <type_traits>
 #include "mi_device.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -84,7 +85,10 @@ template <int VW> __device__ __forceinline__ typename BgVec<VW>::T bg_ldv(const 
 // VW (wgrad only) = pixels per operand load: 1 = element-wise gathers (any plane size); 8 / 4 = 16- / 8-byte loads along the
 // pixels (plane size a multiple of VW; stride 2: output ROW length a multiple of VW).  Forward and dgrad always gather
 // element-wise along the pixels of a wave (see bgemm_stage_vw for what was measured).
-template <int MODE, int KS, int S, int WMW, int VW>
+// SWP (forward / dgrad with 16-byte staging, planes a multiple of 4 pixels, not the strided stride-2 dgrad scatter): the
+// product is taken the other way round (pixels = accumulator rows, channels = columns), so a lane ends up with 4 CONSECUTIVE
+// pixels of ONE output channel per accumulator quad: 8- / 16-byte stores and lane-local BN statistics, no LDS round trip.
+template <int MODE, int KS, int S, int WMW, int VW, int SWP>
 __global__ void __launch_bounds__(256)
 bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__restrict__ OutV, const u16 *__restrict__ addend,
              const BgArgs g) {
@@ -111,20 +115,22 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
     constexpr bool S2W = false; // (stride-2 weight gradients read the parity planes of x: unit stride, one load)
     extern __shared__ __attribute__((aligned(16))) unsigned char bg_smem[];
     unsigned char *As = bg_smem;                         // [2][BM][BG_LDB]
-    unsigned char *Bs = bg_smem + 2 * BM * BG_LDB;       // [2][128][LDBB]
+    unsigned char *Bs = bg_smem + 2 * BM * BG_LDB;       // [2][128][LDBB]  (SWP with a one-k-step reduction: [1][..] each)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = WMW == 2 ? wave >> 1 : 0, wn = WMW == 2 ? wave & 1 : wave;
 
     // ---- block -> tile (XCD-contiguous, M-tiles fastest: the blocks that share a gathered pixel tile share an L2) ----
-    uint32_t L = blockIdx.x;
-    {
+    auto map_tile = [&](uint32_t L, uint32_t &ct_, int &m0_, int &n0_) {
         const uint32_t per = (uint32_t)g.tiles >> 3;
         if (L < per * 8) L = (L & 7) * per + (L >> 3);
-    }
-    const uint32_t ct = fd_div(L, g.fdM);
-    const int m0 = (int)(L - ct * g.mtiles) * BM;
-    const int n0 = (int)ct * 128;
+        ct_ = fd_div(L, g.fdM);
+        m0_ = (int)(L - ct_ * g.mtiles) * BM;
+        n0_ = (int)ct_ * 128;
+    };
+    uint32_t ct;
+    int m0, n0;
+    map_tile(blockIdx.x, ct, m0, n0);
 
     f32x16 acc[2][TN];
 #pragma unroll
@@ -153,6 +159,10 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
             ntaps = (ph ? 2 : 1) * (pw ? 2 : 1);
             ntiles = ntaps * (g.K / BG_BK);
         }
+    }
+    if (SWP && ntiles == 1) Bs = bg_smem + BM * BG_LDB;
+    // forward / dgrad: the staging state of the tile at column n0 (per thread: source offsets and tap masks of its columns)
+    auto tile_state = [&]() {
         // validity of column j's tap t (bit t), and the byte offset of its centre pixel in channel 0 of its image
         auto column = [&](int j, uint32_t &centre) -> uint32_t {
             const uint32_t jc = j < g.ncols ? (uint32_t)j : (uint32_t)g.ncols - 1;
@@ -202,6 +212,7 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
         } else {
             const int col0 = n0 + (tid & 15) * 8;
             uint32_t c0 = 0;
+            vm_lo = 0; vm_hi = 0;
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 uint32_t ce;
@@ -216,6 +227,9 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
             // pointer is lowered to match
             vb_lane = c0 + (uint32_t)(4 * (tid >> 4)) * plane * 2u + BG_BIAS;
         }
+    };
+    if (MODE == BG_FWD || MODE == BG_DGRAD) {
+        tile_state();
     } else {
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -442,15 +456,7 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
     };
 
     const int fr = lane & 31, fk = lane >> 5;
-    fetch();
-    stash(0);
-    fetch();
-    abl_started = true;
-    __syncthreads();
-    for (int it = 0; it < ntiles; it++) {
-        const int buf = it & 1;
-        if (!(BG_ABLATE == 3)) stash(buf ^ 1); // tile it+1 (held in registers) -> the other buffer; then the registers take tile it+2
-        fetch();
+    auto compute = [&](const int buf) {
         const unsigned char *as = As + buf * (BM * BG_LDB) + (wm * 64 + fr) * BG_LDB + fk * 16;
         const unsigned char *bs = Bs + buf * (128 * LDBB) + (wn * WNC + fr) * LDBB + (VB ? 0 : fk * 16);
 #pragma unroll
@@ -474,9 +480,182 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
 #pragma unroll
                 for (int i = 0; i < 2; i++)
 #pragma unroll
-                    for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; j++) {
+                        if constexpr (SWP) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[j], av[i], acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    }
             }
         }
+    };
+    u16 *Out = (u16 *)OutV;
+    const int Mdim = MODE == BG_FWD ? g.K : g.C;
+    const int Pout = MODE == BG_FWD ? g.P : g.HW;
+    const bool stats = MODE == BG_FWD && g.bn_part != nullptr && BG_ABLATE != 7;
+    auto epi_swp = [&]() {
+        // accumulator (i, j): rows = the 32 pixels of column tile j, row (r & 3) + 8 (r >> 2) + 4 (lane >> 5); column = channel
+        // m0 + wm 64 + i 32 + (lane & 31).  A quad r = 4 q .. 4 q + 3 is 4 consecutive pixels: whole or padding (plane % 4 == 0).
+        const int l31 = lane & 31, hh = lane >> 5;
+        uint32_t okm = 0;   // bit j * 4 + q: the quad holds real pixels
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int col = n0 + wn * WNC + j * 32 + 8 * q + 4 * hh;
+                const uint32_t cc = (uint32_t)min(col, g.ncols - 1);
+                const uint32_t n = fd_div(cc, g.fdPc), pp = cc - n * g.Pc;
+                if (col < g.ncols && pp < (uint32_t)g.P) { okm |= 1u << (j * 4 + q); cnt += 4; }
+            }
+        // lane-local BN statistics of the wave's 64 channels x WNC pixels (a lane holds TN * 16 pixels of ONE channel)
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            if (!stats) break;
+            const int m = m0 + wm * 64 + i * 32 + l31;
+            const float s0 = __shfl(acc[i][0][0], l31, 64); // the wave's first pixel (always a real one if any is)
+            float sd = 0.f, sq = 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const bool ok = (okm >> (j * 4 + q)) & 1u;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float d = ok ? acc[i][j][4 * q + e] - s0 : 0.f;
+                        sd += d;
+                        sq = fmaf(d, d, sq);
+                    }
+                }
+            sd += __shfl_xor(sd, 32, 64);
+            sq += __shfl_xor(sq, 32, 64);
+            const int nvw = cnt + __shfl_xor(cnt, 32, 64);
+            if (hh == 0) {
+                constexpr int PPT = 4 / WMW;
+                const float inv = nvw > 0 ? 1.0f / (float)nvw : 0.f;
+                const size_t plane = (size_t)g.bn_np * g.K;
+                const size_t o = (size_t)(ct * PPT + wn) * g.K + m;
+                g.bn_part[o] = (float)nvw;
+                g.bn_part[plane + o] = nvw > 0 ? s0 + sd * inv : 0.f;
+                g.bn_part[2 * plane + o] = fmaxf(sq - sd * sd * inv, 0.f);
+            }
+        }
+        // Stores.  Straight from the accumulators a wave instruction would touch 32 channel rows with 16-32 bytes each, and the
+        // L2 takes one request per piece (measured: the stores alone were 40 % of a short-reduction layer).  So the wave's tile
+        // goes through a wave-private LDS image [64 channels][WNC pixels] (the operand tiles are dead after the loop's last
+        // barrier) and is read back with lanes running ALONG a channel row: a wave instruction then writes whole 128-byte lines.
+        // dgrad keeps fp32 in the image so that the shortcut addend is added before the one rounding to bf16.
+        constexpr bool F32I = MODE == BG_DGRAD;
+        constexpr int ESZ = F32I ? 4 : 2;
+        constexpr int PITCH = WNC * ESZ + 16;
+        constexpr int IROWS = F32I ? 32 : 64;  // channel rows per image: the fp32 image takes the wave's two 32-row halves in turn
+        unsigned char *img = bg_smem + wave * (IROWS * PITCH);
+        auto fill = [&](const int i) {         // accumulators (i, *) -> image rows (F32I ? 0 : 32 i) + lane & 31
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    unsigned char *d = img + ((F32I ? 0 : i * 32) + l31) * PITCH + (j * 32 + 8 * q + 4 * hh) * ESZ;
+                    if constexpr (F32I) {
+                        pf4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        *(pf4 *)d = v;
+                    } else {
+                        u32x2 v = {bg_pack2(acc[i][j][4 * q], acc[i][j][4 * q + 1]), bg_pack2(acc[i][j][4 * q + 2], acc[i][j][4 * q + 3])};
+                        *(u32x2 *)d = v;
+                    }
+                }
+        };
+        auto drain = [&](auto cpx_tag, const int ch0) { // image rows -> channels m0 + wm 64 + ch0 + row
+            constexpr int CPX = decltype(cpx_tag)::value; // pixels per lane and store: 8 (16 bytes) or 4
+            constexpr int CPR = WNC / CPX;                 // lanes along one channel row
+            constexpr int RPP = 64 / CPR;                  // channel rows per wave instruction
+            const int c = lane % CPR, r0 = lane / CPR;
+            const int col = n0 + wn * WNC + c * CPX;
+            const uint32_t cc = (uint32_t)min(col, g.ncols - 1);
+            const uint32_t n = fd_div(cc, g.fdPc), pp = cc - n * g.Pc;
+            const bool ok = col < g.ncols && pp < (uint32_t)g.P; // (a group of CPX pixels is whole or padding)
+            const uint32_t obase = n * (uint32_t)(Mdim * Pout) + pp;
+#pragma unroll
+            for (int ps = 0; ps < IROWS / RPP; ps++) {
+                const int row = ps * RPP + r0;
+                const size_t o = (size_t)(obase + (uint32_t)(m0 + wm * 64 + ch0 + row) * (uint32_t)Pout);
+                const unsigned char *sp = img + row * PITCH + c * CPX * ESZ;
+                uint32_t pk[CPX / 2];
+                if constexpr (F32I) {
+                    float w[CPX];
+#pragma unroll
+                    for (int e = 0; e < CPX / 4; e++) {
+                        const pf4 v = *(const pf4 *)(sp + 16 * e);
+                        w[4 * e] = v[0]; w[4 * e + 1] = v[1]; w[4 * e + 2] = v[2]; w[4 * e + 3] = v[3];
+                    }
+                    if (addend && ok) {
+                        uint32_t ad[CPX / 2];
+                        if constexpr (CPX == 8) { const u32x4 a4 = *(const u32x4 *)(addend + o); ad[0] = a4[0]; ad[1] = a4[1]; ad[2] = a4[2]; ad[3] = a4[3]; }
+                        else { const u32x2 a2 = *(const u32x2 *)(addend + o); ad[0] = a2[0]; ad[1] = a2[1]; }
+#pragma unroll
+                        for (int e = 0; e < CPX / 2; e++) {
+                            w[2 * e] += __uint_as_float(ad[e] << 16);
+                            w[2 * e + 1] += __uint_as_float(ad[e] & 0xffff0000u);
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < CPX / 2; e++) pk[e] = bg_pack2(w[2 * e], w[2 * e + 1]);
+                } else {
+                    if constexpr (CPX == 8) { const u32x4 v = *(const u32x4 *)sp; pk[0] = v[0]; pk[1] = v[1]; pk[2] = v[2]; pk[3] = v[3]; }
+                    else { const u32x2 v = *(const u32x2 *)sp; pk[0] = v[0]; pk[1] = v[1]; }
+                }
+                if (ok) {
+                    if constexpr (CPX == 8) { u32x4 st = {pk[0], pk[1], pk[2], pk[3]}; *(u32x4 *)(Out + o) = st; }
+                    else { u32x2 st = {pk[0], pk[1]}; *(u32x2 *)(Out + o) = st; }
+                }
+            }
+        };
+        auto drain_vw = [&](const int ch0) {
+            if (g.vw == 8) drain(std::integral_constant<int, 8>{}, ch0);
+            else drain(std::integral_constant<int, 4>{}, ch0);
+        };
+        if constexpr (F32I) {
+            fill(0); drain_vw(0);
+            fill(1); drain_vw(32);
+        } else {
+            fill(0); fill(1); drain_vw(0);
+        }
+    };
+    if constexpr (SWP) {
+        // the last two k-steps are peeled off: no loads past the reduction's end (a short reduction -- 1 to 4 k-steps for the 1x1
+        // expansions -- would otherwise wait for two k-steps of loads it never uses), and a one-k-step launch gets by with a
+        // single operand buffer (the host then allocates one: 3 workgroups per CU)
+        fetch();
+        stash(0);
+        if (ntiles > 1) fetch();
+        __syncthreads();
+        int it = 0;
+        for (; it + 2 < ntiles; it++) {
+            const int buf = it & 1;
+            stash(buf ^ 1);
+            fetch();
+            compute(buf);
+            __syncthreads();
+        }
+        if (it + 1 < ntiles) {
+            stash((it & 1) ^ 1);
+            compute(it & 1);
+            __syncthreads();
+            it++;
+        }
+        compute(it & 1);
+        __syncthreads(); // the epilogue re-uses the operand buffers
+        if (BG_ABLATE != 6) epi_swp();
+        return;
+    }
+    fetch();
+    stash(0);
+    fetch();
+    abl_started = true;
+    __syncthreads();
+    for (int it = 0; it < ntiles; it++) {
+        const int buf = it & 1;
+        if (!(BG_ABLATE == 3)) stash(buf ^ 1); // tile it+1 (held in registers) -> the other buffer; then the registers take tile it+2
+        fetch();
+        compute(buf);
         __syncthreads();
     }
 
@@ -500,11 +679,19 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
         }
         return;
     }
-    u16 *Out = (u16 *)OutV;
-    const int Mdim = MODE == BG_FWD ? g.K : g.C;
-    const int Pout = MODE == BG_FWD ? g.P : g.HW;
+    if (BG_ABLATE == 6) { /* experiment: no epilogue at all */
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) sacc += acc[i][j][r];
+        if (sacc == 1.2345678f) Out[0] = 1;
+        return;
+    }
+
     const bool wide = g.vw > 1 && !(MODE == BG_DGRAD && S == 2);
-    const bool stats = MODE == BG_FWD && g.bn_part != nullptr;
     if (wide || stats) {
         // each wave transposes 64 rows x 32 columns at a time through its own 8 KB of LDS (the tiles are dead after the
         // loop's last barrier): lane = row then owns 32 consecutive columns
@@ -782,26 +969,39 @@ static void bgemm_geometry(BgArgs &g, int N, int C, int H, int K, int stride) {
     g.fdP = make_fastdiv(g.P); g.fdWo = make_fastdiv(g.Wo); g.fdPc = g.fdP;
     g.fdCb = make_fastdiv(1);
 }
-template <int MODE, int KS, int S, int WMW, int VW>
+template <int MODE, int KS, int S, int WMW, int VW, int SWP = 0>
 static int bgemm_launch_t(hipStream_t st, dim3 grid, const u16 *A, const u16 *B, void *out, const u16 *addend, const BgArgs &g) {
     constexpr int BM = 64 * WMW;
     constexpr size_t ldbb = (MODE != BG_WGRAD && VW == 8) ? 160 : BG_LDB;
     constexpr size_t tiles_b = (size_t)2 * (BM * BG_LDB + 128 * ldbb), ep_b = (size_t)4 * 32 * 64 * 4;
-    constexpr size_t lds = tiles_b > ep_b ? tiles_b : ep_b;
+    size_t lds = tiles_b > ep_b ? tiles_b : ep_b;
+    if (SWP) { // its epilogue image (<= 36 KB) fits one operand buffer; a one-k-step reduction uses one buffer only
+        const int ksteps = (MODE == BG_FWD ? g.C : g.K) / BG_BK * KS * KS;
+        lds = ksteps == 1 ? tiles_b / 2 : tiles_b;
+    }
     static int attr_set = 0;
     if (!attr_set) {
         if (lds > 64 * 1024 &&
-            hipFuncSetAttribute((const void *)bgemm_kernel<MODE, KS, S, WMW, VW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            hipFuncSetAttribute((const void *)bgemm_kernel<MODE, KS, S, WMW, VW, SWP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             mi_record_error("bgemm_kernel", "cannot raise the dynamic LDS limit");
             return -1;
         }
         attr_set = 1;
     }
-    hipLaunchKernelGGL((bgemm_kernel<MODE, KS, S, WMW, VW>), grid, dim3(256), lds, st, A, B, out, addend, g);
+    hipLaunchKernelGGL((bgemm_kernel<MODE, KS, S, WMW, VW, SWP>), grid, dim3(256), lds, st, A, B, out, addend, g);
     return 0;
 }
 template <int MODE, int KS, int S>
 static int bgemm_launch_v(hipStream_t st, dim3 grid, const u16 *A, const u16 *B, void *out, const u16 *addend, const BgArgs &g, int bm, int vw) {
+    // the pixel-major product (SWP): 16-byte staging, planes a multiple of 4 pixels, contiguous output pixels
+    static int swp_on = -1;
+    if (swp_on < 0) { const char *e = getenv("RESNET_MI_BF16_SWP"); swp_on = e ? atoi(e) : 1; }
+    if constexpr (MODE != BG_WGRAD && !(MODE == BG_DGRAD && S == 2)) {
+        if (vw == 8 && g.vw > 1 && swp_on) {
+            if (bm == 128) return bgemm_launch_t<MODE, KS, S, 2, 8, 1>(st, grid, A, B, out, addend, g);
+            return bgemm_launch_t<MODE, KS, S, 1, 8, 1>(st, grid, A, B, out, addend, g);
+        }
+    }
     if (bm == 128) {
         if (vw == 8) return bgemm_launch_t<MODE, KS, S, 2, 8>(st, grid, A, B, out, addend, g);
         if (vw == 4) return bgemm_launch_t<MODE, KS, S, 2, 4>(st, grid, A, B, out, addend, g);
