@@ -39,6 +39,7 @@
 // predicated.  Block ids are re-mapped so that each XCD walks a contiguous range of tiles, M-tiles fastest: the blocks that
 // share a gathered pixel tile share an L2.
 #include "mi_common.hpp"
+#include <type_traits>
 #include "mi_device.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -379,11 +380,12 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
     for (int q = 0; q < 4; q++) { if (VB) asm volatile("" : "+v"(rb4[q])); }
     __syncthreads();
     IG_T(1);
-    for (int it = 0; it < ntiles; it++) {
-        const int buf = it & 1;
-        // The registers hold tile it+1: it goes to the other buffer, then the registers are refilled with tile it+2.
-        constexpr bool st = IG_ABLATE != 1;
-        constexpr bool ft = IG_ABLATE != 1 && IG_ABLATE != 4;
+    // One k-step: the registers hold tile it+1, which goes to the other buffer (STASH), then they are refilled with tile it+2
+    // (FETCH).  The last two k-steps run without the fetch / without both (peeled below): a short reduction (2-8 k-steps for the
+    // 1x1 expansions) no longer moves two k-steps of operands nobody reads, and the main loop stays free of branches.
+    auto kstep = [&](auto st_tag, auto ft_tag, const int buf) {
+        constexpr bool st = IG_ABLATE != 1 && decltype(st_tag)::value;
+        constexpr bool ft = IG_ABLATE != 1 && IG_ABLATE != 4 && decltype(ft_tag)::value;
         const float *as = As + buf * IG_BK * LDA + fk * LDA + wm * 64 + fr;
         const float *bs = Bs + buf * IG_BK * LDB + fk * LDB + wn * WNC + fr;
         // fragments of step k2+2 are read while the MFMAs of step k2 run
@@ -412,6 +414,14 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
+    };
+    {
+        constexpr std::true_type Y{};
+        constexpr std::false_type NO{};
+        int it = 0;
+        for (; it + 2 < ntiles; it++) kstep(Y, Y, it & 1);
+        if (it + 1 < ntiles) { kstep(Y, NO, it & 1); it++; }
+        if (it < ntiles) kstep(NO, NO, it & 1);
     }
 
     IG_T(2);

@@ -246,10 +246,13 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
     }
 
     // registers of the tile in flight
-    u32x4 ra4[NA];
+    // SWP 3x3: TWO k-steps of loads in flight (two register sets: +3-6 % on the 3x3 layers; the 1x1 layers gained nothing and a
+    // one-k-step launch lost its third resident workgroup to the registers)
+    constexpr int NSET = (SWP && KS == 3) ? 2 : 1;
+    u32x4 ra4[NSET][NA];
     u16 ra[NAS], rb[32];
-    u32x4 vb[4];                            // VB: 8 pixels of 4 adjacent channels
-    uint32_t vmask = 0;
+    u32x4 vb[NSET][4];                      // VB: 8 pixels of 4 adjacent channels
+    uint32_t vmask[NSET] = {};
     LT wa[NAU], wb[NBU][S2W ? 2 : 1];       // VEC wgrad
     uint32_t wmask[NBU], wamask = 0;
     int sel_a = 1, sel_b = 1;
@@ -258,7 +261,10 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
     auto ldg16 = [](const char *ubase, uint32_t lane_off) -> u16 { return *(const u16 *)(ubase + lane_off); };
 
     bool abl_started = false;
-    auto fetch = [&]() {
+    constexpr std::integral_constant<int, 0> I0{};
+    constexpr std::integral_constant<int, NSET - 1> I1{};
+    auto fetch = [&](auto set_tag) {
+        constexpr int SET = decltype(set_tag)::value;
         if (MODE == BG_FWD || MODE == BG_DGRAD) {
             const int t = min(ld_t, ntaps - 1); // the two drain iterations re-read the last tap
             sel_b = (mask >> t) & 1;
@@ -298,16 +304,16 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
 #pragma unroll
                 for (int q = 0; q < 32; q++) rb[q] = ldg16(fb + (size_t)q * bstride, fb_lane);
             } else {
-                vmask = t < 8 ? (uint32_t)(vm_lo >> (8 * t)) & 0xffu : vm_hi;
-                const uint32_t off = vb_lane + (uint32_t)((vmask ? shift : 0) * 2); // no valid pixel at all: stay on the centre
+                vmask[SET] = t < 8 ? (uint32_t)(vm_lo >> (8 * t)) & 0xffu : vm_hi;
+                const uint32_t off = vb_lane + (uint32_t)((vmask[SET] ? shift : 0) * 2); // no valid pixel at all: stay on the centre
                 // two passes of 4 channels: this thread's channels 4 cq .. 4 cq + 3 and + 64 would be the next tile, so the
                 // 64-channel tile is covered by cq = 0..15 with 4 channels each
 #pragma unroll
-                for (int c = 0; c < 4; c++) vb[c] = bg_ldv<8>(fb - BG_BIAS + (size_t)c * bstride + off);
+                for (int c = 0; c < 4; c++) vb[SET][c] = bg_ldv<8>(fb - BG_BIAS + (size_t)c * bstride + off);
             }
             if (!(BG_ABLATE >= 2 && BG_ABLATE <= 3 && abl_started)) {
 #pragma unroll
-                for (int q = 0; q < NA; q++) ra4[q] = *(const u32x4 *)(fa + (size_t)(tid + 256 * q) * 16);
+                for (int q = 0; q < NA; q++) ra4[SET][q] = *(const u32x4 *)(fa + (size_t)(tid + 256 * q) * 16);
             }
         } else if (!VEC) {
             const int kk = ld_k0 + (tid & 63);
@@ -393,7 +399,8 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
         }
         return o;
     };
-    auto stash = [&](const int buf) {
+    auto stash = [&](auto set_tag, const int buf) {
+        constexpr int SET = decltype(set_tag)::value;
         unsigned char *as = As + buf * (BM * BG_LDB), *bs = Bs + buf * (128 * LDBB);
         if (MODE == BG_WGRAD) {
             if (!VEC) {
@@ -437,10 +444,10 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
                 const int g8 = tid & 15, cq = tid >> 4;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    u32x2 e0 = {__builtin_amdgcn_perm(vb[1][j], vb[0][j], 0x05040100u), __builtin_amdgcn_perm(vb[3][j], vb[2][j], 0x05040100u)};
-                    u32x2 e1 = {__builtin_amdgcn_perm(vb[1][j], vb[0][j], 0x07060302u), __builtin_amdgcn_perm(vb[3][j], vb[2][j], 0x07060302u)};
-                    if (!((vmask >> (2 * j)) & 1u)) { e0[0] = 0u; e0[1] = 0u; }
-                    if (!((vmask >> (2 * j + 1)) & 1u)) { e1[0] = 0u; e1[1] = 0u; }
+                    u32x2 e0 = {__builtin_amdgcn_perm(vb[SET][1][j], vb[SET][0][j], 0x05040100u), __builtin_amdgcn_perm(vb[SET][3][j], vb[SET][2][j], 0x05040100u)};
+                    u32x2 e1 = {__builtin_amdgcn_perm(vb[SET][1][j], vb[SET][0][j], 0x07060302u), __builtin_amdgcn_perm(vb[SET][3][j], vb[SET][2][j], 0x07060302u)};
+                    if (!((vmask[SET] >> (2 * j)) & 1u)) { e0[0] = 0u; e0[1] = 0u; }
+                    if (!((vmask[SET] >> (2 * j + 1)) & 1u)) { e1[0] = 0u; e1[1] = 0u; }
                     const int r0 = 8 * g8 + 2 * j, r1 = r0 + 1; // r0 >> 4 == r1 >> 4 == g8 >> 1
                     const int chunk = ((cq >> 1) + (g8 >> 1)) & 7;
                     *(u32x2 *)(bs + r0 * LDBB + chunk * 16 + (cq & 1) * 8) = e0;
@@ -450,7 +457,7 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
 #pragma unroll
             for (int q = 0; q < NA; q++) {
                 const int u = tid + 256 * q;
-                *(u32x4 *)(as + (u >> 3) * BG_LDB + (u & 7) * 16) = ra4[q];
+                if (!(BG_ABLATE == 8)) *(u32x4 *)(as + (u >> 3) * BG_LDB + (u & 7) * 16) = ra4[SET][q];
             }
         }
     };
@@ -463,7 +470,10 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
         for (int s = 0; s < BG_BK / 16; s++) {
             bf16x8 av[2], bv[TN];
 #pragma unroll
-            for (int i = 0; i < 2; i++) av[i] = *(const bf16x8 *)(as + i * 32 * BG_LDB + s * 32);
+            for (int i = 0; i < 2; i++) {
+                if (BG_ABLATE == 8 && MODE != BG_WGRAD) { u32x4 t = ra4[0][(2 * i + s) % NA]; av[i] = *(bf16x8 *)&t; } /* experiment: A operand without LDS */
+                else av[i] = *(const bf16x8 *)(as + i * 32 * BG_LDB + s * 32);
+            }
 #pragma unroll
             for (int j = 0; j < TN; j++) {
                 if (VB) { // chunk (2 s + fk) of the row, rotated by (row >> 4)
@@ -620,41 +630,60 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
         }
     };
     if constexpr (SWP) {
-        // the last two k-steps are peeled off: no loads past the reduction's end (a short reduction -- 1 to 4 k-steps for the 1x1
-        // expansions -- would otherwise wait for two k-steps of loads it never uses), and a one-k-step launch gets by with a
-        // single operand buffer (the host then allocates one: 3 workgroups per CU)
-        fetch();
-        stash(0);
-        if (ntiles > 1) fetch();
-        __syncthreads();
-        int it = 0;
-        for (; it + 2 < ntiles; it++) {
-            const int buf = it & 1;
-            stash(buf ^ 1);
-            fetch();
-            compute(buf);
+        // No loads past the reduction's end (a short reduction -- 1 to 4 k-steps for the 1x1 expansions -- would otherwise wait for loads it never
+        // uses); a one-k-step launch gets by with a single operand buffer (the host then allocates one: 3 workgroups per CU)
+        if constexpr (NSET == 2) {
+            fetch(I0);                  // k-step 0
+            if (ntiles > 1) fetch(I1);  // k-step 1
+            stash(I0, 0);
+            if (ntiles > 2) fetch(I0);  // k-step 2
             __syncthreads();
-        }
-        if (it + 1 < ntiles) {
-            stash((it & 1) ^ 1);
+            int it = 0;
+            for (; it + 4 < ntiles; it += 2) { // k-step it from LDS, it + 1 -> LDS, it + 2 in flight, it + 3 issued
+                stash(I1, 1); fetch(I1); compute(0); __syncthreads();
+                stash(I0, 0); fetch(I0); compute(1); __syncthreads();
+            }
+            for (; it < ntiles; it++) {
+                const int buf = it & 1;
+                if (it + 1 < ntiles) { if (buf) stash(I0, 0); else stash(I1, 1); }
+                if (it + 3 < ntiles) { if (buf) fetch(I0); else fetch(I1); }
+                compute(buf);
+                if (it + 1 < ntiles) __syncthreads();
+            }
+        } else {
+            fetch(I0);
+            stash(I0, 0);
+            if (ntiles > 1) fetch(I0);
+            __syncthreads();
+            int it = 0;
+            for (; it + 2 < ntiles; it++) {
+                const int buf = it & 1;
+                stash(I0, buf ^ 1);
+                fetch(I0);
+                compute(buf);
+                __syncthreads();
+            }
+            if (it + 1 < ntiles) {
+                stash(I0, (it & 1) ^ 1);
+                compute(it & 1);
+                __syncthreads();
+                it++;
+            }
             compute(it & 1);
-            __syncthreads();
-            it++;
         }
-        compute(it & 1);
         __syncthreads(); // the epilogue re-uses the operand buffers
         if (BG_ABLATE != 6) epi_swp();
         return;
     }
-    fetch();
-    stash(0);
-    fetch();
+    fetch(I0);
+    stash(I0, 0);
+    fetch(I0);
     abl_started = true;
     __syncthreads();
     for (int it = 0; it < ntiles; it++) {
         const int buf = it & 1;
-        if (!(BG_ABLATE == 3)) stash(buf ^ 1); // tile it+1 (held in registers) -> the other buffer; then the registers take tile it+2
-        fetch();
+        if (!(BG_ABLATE == 3)) stash(I0, buf ^ 1); // tile it+1 (held in registers) -> the other buffer; then the registers take tile it+2
+        fetch(I0);
         compute(buf);
         __syncthreads();
     }
