@@ -377,6 +377,11 @@ int mi_op_conv_fwd_bf16(const void *x_bf16, const float *w_kcrs, void *y_bf16, i
 int mi_op_conv_dgrad_bf16(const float *w_kcrs, const void *dy_bf16, void *dx_bf16, int N, int C, int H, int K, int k, int stride,
                           int to_add);
 int mi_op_conv_wgrad_bf16(const void *x_bf16, const void *dy_bf16, float *dw_kcrs, int N, int C, int H, int K, int k, int stride);
+/* prepareAndDoConvolution + prepareAndDoBatchNormAndActivate as forward_pass pairs them (resnet.cu:1386-1396, 1431-1453): BN
+ * statistics from the convolution's own epilogue where the layer runs on the implicit GEMM.  dt = storage type of x, conv_out, y.
+ * Returns < 0 on error, else the number of statistics partial rows the convolution left (0 = separate statistics pass). */
+int mi_op_conv_bn_fwd_t(const void *x, const float *w_kcrs, void *conv_out, int dt, const float *gamma, const float *beta,
+                        float *means, float *vars, void *y, int N, int C, int H, int K, int k, int stride, float eps, int relu);
 int mi_op_bn_fwd_t(const void *x, int x_dt, const float *gamma, const float *beta, const void *residual, float *means, float *vars,
                    void *y, int a_dt, int N, int C, int H, float eps, int relu);
 int mi_op_bn_apply_t(const void *x, int x_dt, const float *gamma, const float *beta, const void *residual, const float *means,

@@ -139,6 +139,31 @@ int mi_op_conv_wgrad_bf16(const void *x, const void *dy, float *dw, int N, int C
     ws_free(&ws);
     return rc;
 }
+/* A convolution and the batch norm behind it the way forward_pass runs the pair (resnet.cu:1386-1396 + 1431-1453): the
+ * statistics come out of the convolution's own epilogue (fp32 accumulators) where the layer runs on the implicit GEMM, and
+ * from a pass over conv_out where it does not.  dt = storage type of x, conv_out and y. */
+int mi_op_conv_bn_fwd_t(const void *x, const float *w, void *conv_out, int dt, const float *gamma, const float *beta, float *means,
+                        float *vars, void *y, int N, int C, int H, int K, int k, int stride, float eps, int relu) {
+    mid_workspace ws;
+    const int Ho = H / stride;
+    if (ws_make(&ws, dt == MID_BF16 ? (size_t)k * k * C * K : mid_conv_ws_wt_floats(C, K, k), 0)) return -3;
+    mid_bn_parts parts = {NULL, mid_bn_parts_floats(N, K, Ho), 0};
+    parts.buf = (float *)mid_malloc(parts.floats * sizeof(float));
+    float *bws = (float *)mid_malloc(mid_bn_ws_floats(K) * sizeof(float));
+    void *par = NULL;
+    int rc;
+    if (dt == MID_BF16) {
+        if (stride == 2) { ws.s2d_bytes = (size_t)N * C * H * H * 2; par = mi_malloc(ws.s2d_bytes); ws.s2d = par; }
+        rc = mid_conv_fwd_bf16(mi_global()->compute, &ws, x, w, conv_out, N, C, H, K, k, stride, &parts);
+    } else rc = mid_conv_fwd_stats(mi_global()->compute, &ws, (const float *)x, w, (float *)conv_out, N, C, H, K, k, stride, &parts);
+    if (!rc) rc = mid_bn_fwd_t(mi_global()->compute, bws, &parts, conv_out, dt, gamma, beta, NULL, means, vars, y, dt, NULL, NULL, N, K, Ho * Ho, eps, relu);
+    rc = finish(rc);
+    mi_free(par);
+    mid_free(bws);
+    mid_free(parts.buf);
+    ws_free(&ws);
+    return rc < 0 ? rc : parts.nparts; /* > 0: the statistics were fused (number of partial rows), 0: separate pass */
+}
 int mi_op_bn_fwd_t(const void *x, int x_dt, const float *gamma, const float *beta, const void *residual, float *means, float *vars,
                    void *y, int a_dt, int N, int C, int H, float eps, int relu) {
     float *ws = (float *)mid_malloc(mid_bn_ws_floats(C) * sizeof(float));

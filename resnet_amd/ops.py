@@ -231,6 +231,19 @@ class Ops:
                                         int(relu)), "bn_fwd_t")
         return dm.get(), dv.get(), self.get_t(dy, a_dt)
 
+    def conv_bn_fwd_t(self, x, w, gamma, beta, stride, eps, relu, dt):
+        """conv + BN as forward_pass pairs them; returns conv_out, means, vars, y and whether the statistics were fused"""
+        N, Cc, H, _ = x.shape
+        K, _, k, _ = w.shape
+        Ho = H // stride
+        dx, dw, dg, db = self.dev_t(x, dt), self.dev(w), self.dev(gamma), self.dev(beta)
+        dc, dy = self.new_t((N, K, Ho, Ho), dt), self.new_t((N, K, Ho, Ho), dt)
+        dm, dv = self.dev(shape=(K,)), self.dev(shape=(K,))
+        rc = self.L.mi_op_conv_bn_fwd_t(dx.ptr, dw.ptr, dc.ptr, dt, dg.ptr, db.ptr, dm.ptr, dv.ptr, dy.ptr, N, Cc, H, K, k, stride, eps, int(relu))
+        if rc < 0:
+            self._chk(rc, "conv_bn_fwd_t")
+        return self.get_t(dc, dt), dm.get(), dv.get(), self.get_t(dy, dt), rc > 0
+
     def bn_apply_t(self, x, gamma, beta, means, vars_, eps, relu, x_dt, a_dt, residual=None):
         N, Cc, H, _ = x.shape
         dx, dg, db, dm, dv = self.dev_t(x, x_dt), self.dev(gamma), self.dev(beta), self.dev(means), self.dev(vars_)

@@ -108,6 +108,55 @@ def test_conv_wgrad_bf16(ops, oracle, shape):
     check_grad(got, ref, "conv_wgrad_bf16 %s" % (shape,))
 
 
+# conv + BN the way forward_pass pairs them: BN statistics from the convolution's epilogue.  Every plane size of the benchmark
+# network (16-byte, 8-byte and scalar store paths; one-k-step reductions; 64-row tiles) plus ragged small ones.
+CONV_BN_SHAPES = [
+    (64, 56, 64, 3, 1, 2),
+    (64, 56, 256, 1, 1, 2),      # one k-step: single operand buffer
+    (256, 56, 64, 1, 1, 2),      # 64 output channels: 64-row tiles
+    (128, 28, 128, 3, 1, 3),
+    (128, 28, 512, 1, 1, 2),
+    (256, 14, 1024, 1, 1, 3),    # P = 196: 8-byte stores
+    (256, 14, 256, 3, 1, 3),
+    (512, 14, 512, 3, 2, 2),     # output 7x7: scalar stores
+    (512, 7, 2048, 1, 1, 5),
+    (256, 56, 512, 3, 2, 1),     # projection (parity planes)
+    (64, 10, 64, 1, 1, 3),       # P = 100, 300 columns
+    (128, 6, 64, 3, 1, 5),       # P = 36
+    (64, 8, 256, 1, 1, 1),       # fewer columns than one tile
+]
+
+
+@pytest.mark.parametrize("dt", [BF16, F32], ids=["bf16", "f32"])
+@pytest.mark.parametrize("shape", CONV_BN_SHAPES, ids=["C%d_H%d_K%d_k%d_s%d_N%d" % s for s in CONV_BN_SHAPES])
+def test_conv_bn_pair_statistics_from_the_conv_epilogue(ops, oracle, shape, dt):
+    C, H, K, k, stride, N = shape
+    eps = 1e-7
+    x, w, _ = _conv_data(*shape)
+    if dt == F32:
+        x = rand((N, H, H, C), 7)
+    gamma = (1 + 0.2 * rand((K,), 4)).astype(np.float32)
+    beta = (0.3 * rand((K,), 5)).astype(np.float32)
+    conv = oracle.conv_fwd(x, bf16_round(w) if dt == BF16 else w, stride)
+    got_conv, gm, gv, gy, fused = ops.conv_bn_fwd_t(nchw(x), w, gamma, beta, stride, eps, 1, dt)
+    assert fused, "this shape tiles: the statistics must come from the convolution's epilogue"
+    # the statistics are those of the fp32 accumulators (before any rounding of the stored tensor)
+    means, vars_, _, _, _ = oracle.bn_fwd(conv, gamma, beta, eps, 1)
+    check_grad(gm, means, "fused means %s" % (shape,), rel=2e-5)
+    check_grad(gv, vars_, "fused vars %s" % (shape,), rel=1e-4)
+    if dt == BF16:
+        check_bf(nhwc(got_conv), conv, "conv out")
+        # BN applied to the STORED (rounded) tensor with those statistics
+        stored = nhwc(got_conv)
+        sd = np.sqrt(gv.astype(np.float64) + eps)
+        ref_y = np.maximum(gamma * ((stored.astype(np.float64) - gm) / sd) + beta, 0)
+        check_bf(nhwc(gy), ref_y.astype(np.float32), "bn(conv) out")
+    else:
+        _, _, _, _, act = oracle.bn_fwd(conv, gamma, beta, eps, 1)
+        assert rel_l2(nhwc(got_conv), conv) <= 1e-5
+        assert rel_l2(nhwc(gy), act) <= 2e-5
+
+
 def test_bf16_kernels_refuse_shapes_that_do_not_tile(ops):
     x, w = rand((2, 3, 32, 32), 1), rand((64, 3, 7, 7), 2)
     assert ops.L.mi_bf16_conv_supported(0, 2, 3, 32, 64, 7, 2) == 0
