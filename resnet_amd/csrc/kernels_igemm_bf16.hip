@@ -88,7 +88,9 @@ template <int VW> __device__ __forceinline__ typename BgVec<VW>::T bg_ldv(const 
 // SWP (forward / dgrad with 16-byte staging, planes a multiple of 4 pixels, not the strided stride-2 dgrad scatter): the
 // product is taken the other way round (pixels = accumulator rows, channels = columns), so a lane ends up with 4 CONSECUTIVE
 // pixels of ONE output channel per accumulator quad: 8- / 16-byte stores and lane-local BN statistics, no LDS round trip.
-template <int MODE, int KS, int S, int WMW, int VW, int SWP>
+// SBUF (SWP only): ONE operand buffer, two barriers per k-step, the next k-step's loads held in registers across the multiply:
+// half the LDS, so THREE workgroups per CU.  Wins where the tile count fills 768 slots about as well as 512 (bgemm_single_buffer).
+template <int MODE, int KS, int S, int WMW, int VW, int SWP, int SBUF>
 __global__ void __launch_bounds__(256)
 bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__restrict__ OutV, const u16 *__restrict__ addend,
              const BgArgs g) {
@@ -106,6 +108,7 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
     // conflict-free, the transposing ds_write_b64 are 2-way (tools: the search in DESIGN.md section 7).
     constexpr bool VB = MODE != BG_WGRAD && VW == 8;
     constexpr int LDBB = VB ? 160 : BG_LDB;   // pitch of the B image
+    constexpr bool SB = SWP && SBUF;
     typedef typename BgVec<VW>::T LT;
     constexpr int LW = VW / 2;               // dwords per vector load
     // wgrad vector staging: a unit = VW pixels of one row; BG_BK / VW units per 64-pixel row
@@ -160,7 +163,7 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
             ntiles = ntaps * (g.K / BG_BK);
         }
     }
-    if (SWP && ntiles == 1) Bs = bg_smem + BM * BG_LDB;
+    if (SWP && (ntiles == 1 || SB)) Bs = bg_smem + BM * BG_LDB;
     // forward / dgrad: the staging state of the tile at column n0 (per thread: source offsets and tap masks of its columns)
     auto tile_state = [&]() {
         // validity of column j's tap t (bit t), and the byte offset of its centre pixel in channel 0 of its image
@@ -248,7 +251,7 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
     // registers of the tile in flight
     // SWP 3x3: TWO k-steps of loads in flight (two register sets: +3-6 % on the 3x3 layers; the 1x1 layers gained nothing and a
     // one-k-step launch lost its third resident workgroup to the registers)
-    constexpr int NSET = (SWP && KS == 3) ? 2 : 1;
+    constexpr int NSET = (SWP && KS == 3 && !SB) ? 2 : 1;
     u32x4 ra4[NSET][NA];
     u16 ra[NAS], rb[32];
     u32x4 vb[NSET][4];                      // VB: 8 pixels of 4 adjacent channels
@@ -632,7 +635,27 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
     if constexpr (SWP) {
         // No loads past the reduction's end (a short reduction -- 1 to 4 k-steps for the 1x1 expansions -- would otherwise wait for loads it never
         // uses); a one-k-step launch gets by with a single operand buffer (the host then allocates one: 3 workgroups per CU)
-        if constexpr (NSET == 2) {
+        if constexpr (SB) {
+            fetch(I0);
+            stash(I0, 0);
+            if (ntiles > 1) fetch(I0);
+            __syncthreads();
+            int it = 0;
+            for (; it + 2 < ntiles; it++) {
+                compute(0);
+                __syncthreads();
+                stash(I0, 0);
+                fetch(I0);
+                __syncthreads();
+            }
+            if (it + 1 < ntiles) {
+                compute(0);
+                __syncthreads();
+                stash(I0, 0);
+                __syncthreads();
+            }
+            compute(0);
+        } else if constexpr (NSET == 2) {
             fetch(I0);                  // k-step 0
             if (ntiles > 1) fetch(I1);  // k-step 1
             stash(I0, 0);
@@ -998,7 +1021,7 @@ static void bgemm_geometry(BgArgs &g, int N, int C, int H, int K, int stride) {
     g.fdP = make_fastdiv(g.P); g.fdWo = make_fastdiv(g.Wo); g.fdPc = g.fdP;
     g.fdCb = make_fastdiv(1);
 }
-template <int MODE, int KS, int S, int WMW, int VW, int SWP = 0>
+template <int MODE, int KS, int S, int WMW, int VW, int SWP = 0, int SBUF = 0>
 static int bgemm_launch_t(hipStream_t st, dim3 grid, const u16 *A, const u16 *B, void *out, const u16 *addend, const BgArgs &g) {
     constexpr int BM = 64 * WMW;
     constexpr size_t ldbb = (MODE != BG_WGRAD && VW == 8) ? 160 : BG_LDB;
@@ -1006,19 +1029,33 @@ static int bgemm_launch_t(hipStream_t st, dim3 grid, const u16 *A, const u16 *B,
     size_t lds = tiles_b > ep_b ? tiles_b : ep_b;
     if (SWP) { // its epilogue image (<= 36 KB) fits one operand buffer; a one-k-step reduction uses one buffer only
         const int ksteps = (MODE == BG_FWD ? g.C : g.K) / BG_BK * KS * KS;
-        lds = ksteps == 1 ? tiles_b / 2 : tiles_b;
+        lds = (ksteps == 1 || SBUF) ? tiles_b / 2 : tiles_b;
     }
     static int attr_set = 0;
     if (!attr_set) {
         if (lds > 64 * 1024 &&
-            hipFuncSetAttribute((const void *)bgemm_kernel<MODE, KS, S, WMW, VW, SWP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            hipFuncSetAttribute((const void *)bgemm_kernel<MODE, KS, S, WMW, VW, SWP, SBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             mi_record_error("bgemm_kernel", "cannot raise the dynamic LDS limit");
             return -1;
         }
         attr_set = 1;
     }
-    hipLaunchKernelGGL((bgemm_kernel<MODE, KS, S, WMW, VW, SWP>), grid, dim3(256), lds, st, A, B, out, addend, g);
+    hipLaunchKernelGGL((bgemm_kernel<MODE, KS, S, WMW, VW, SWP, SBUF>), grid, dim3(256), lds, st, A, B, out, addend, g);
     return 0;
+}
+// One operand buffer and three resident workgroups per CU (768 slots), or two buffers and two (512)?  Measured per layer at
+// N = 256 (tools/bench_ops.py --bf16): with every slot busy three workgroups deliver about 1.1x (3x3: the two-buffer form also
+// keeps two k-steps of loads in flight) to 1.2x (1x1) the throughput of two, so the choice is the one whose LAST ROUND of
+// workgroups is fuller: 3x3 @56 (6272 tiles) 0.167 -> 0.138 ms, the 256->512 / 512->1024 projections 0.71 -> 0.66-0.68, but
+// 256 ch @14 (800 tiles: 1.04 rounds of 768) 0.114 -> 0.120.  RESNET_MI_BF16_SBUF=0|1 forces it.
+static int bgemm_single_buffer(int tiles, int ks) {
+    static int force = -1;
+    if (force < 0) { const char *e = getenv("RESNET_MI_BF16_SBUF"); force = e ? atoi(e) : 2; }
+    if (force == 0 || force == 1) return force;
+    const double gain = ks == 1 ? 1.2 : 1.1;
+    const double t2 = (double)((tiles + BG_SLOTS - 1) / BG_SLOTS) * 2.0;
+    const double t3 = (double)((tiles + 767) / 768) * 3.0 / gain;
+    return t3 < t2;
 }
 template <int MODE, int KS, int S>
 static int bgemm_launch_v(hipStream_t st, dim3 grid, const u16 *A, const u16 *B, void *out, const u16 *addend, const BgArgs &g, int bm, int vw) {
@@ -1027,6 +1064,10 @@ static int bgemm_launch_v(hipStream_t st, dim3 grid, const u16 *A, const u16 *B,
     if (swp_on < 0) { const char *e = getenv("RESNET_MI_BF16_SWP"); swp_on = e ? atoi(e) : 1; }
     if constexpr (MODE != BG_WGRAD && !(MODE == BG_DGRAD && S == 2)) {
         if (vw == 8 && g.vw > 1 && swp_on) {
+            if (bgemm_single_buffer(g.tiles, KS)) {
+                if (bm == 128) return bgemm_launch_t<MODE, KS, S, 2, 8, 1, 1>(st, grid, A, B, out, addend, g);
+                return bgemm_launch_t<MODE, KS, S, 1, 8, 1, 1>(st, grid, A, B, out, addend, g);
+            }
             if (bm == 128) return bgemm_launch_t<MODE, KS, S, 2, 8, 1>(st, grid, A, B, out, addend, g);
             return bgemm_launch_t<MODE, KS, S, 1, 8, 1>(st, grid, A, B, out, addend, g);
         }
