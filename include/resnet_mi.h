@@ -377,6 +377,11 @@ int mi_op_conv_fwd_bf16(const void *x_bf16, const float *w_kcrs, void *y_bf16, i
 int mi_op_conv_dgrad_bf16(const float *w_kcrs, const void *dy_bf16, void *dx_bf16, int N, int C, int H, int K, int k, int stride,
                           int to_add);
 int mi_op_conv_wgrad_bf16(const void *x_bf16, const void *dy_bf16, float *dw_kcrs, int N, int C, int H, int K, int k, int stride);
+/* the stem convolution of the bf16 storage mode (7x7 stride 2, 3 -> 64 filters, H a multiple of 32; doConvolution /
+ * convolutionDerivWeights, resnet.cu:109-156, 227-281): fp32 tensors in and out, image and weights rounded to bf16 inside,
+ * fp32 accumulation on the bf16 matrix cores.  -2: shape not covered (the trainer then keeps the fp32 stem). */
+int mi_op_stem_fwd_bf16(const float *x, const float *w_kcrs, float *y, int N, int H);
+int mi_op_stem_wgrad_bf16(const float *x, const float *w_kcrs, const float *dy, float *dw_kcrs, int N, int H);
 /* prepareAndDoConvolution + prepareAndDoBatchNormAndActivate as forward_pass pairs them (resnet.cu:1386-1396, 1431-1453): BN
  * statistics from the convolution's own epilogue where the layer runs on the implicit GEMM.  dt = storage type of x, conv_out, y.
  * Returns < 0 on error, else the number of statistics partial rows the convolution left (0 = separate statistics pass). */

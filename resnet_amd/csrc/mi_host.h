@@ -65,6 +65,8 @@ typedef struct MiCtx {
     size_t *alloc_bytes;
     float *rc_buf[2];            /* RECOMPUTE_BN: scratch for the BN(+ReLU) tensors (forward: consumed at once; backward: re-derived) */
     float *stem_dx;              /* bf16 mode: the stem convolution's output gradient stays fp32 */
+    void *stem_xp; size_t stem_xp_bytes;           /* bf16 mode: the batch as zero-padded bf16 parity planes (kernels_stem_bf16.hip) */
+    float *stem_scratch; size_t stem_scratch_floats; /*            its wave partials + re-laid weights; NULL = the fp32 stem kernels */
     int counting_act;
     int overlap_set;             /* mi_trainer_set_overlap was called: keep the caller's mode */
     MiParity *par;               /* bf16: per block, NULL buffers for blocks that do not stride */

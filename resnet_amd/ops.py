@@ -231,6 +231,18 @@ class Ops:
                                         int(relu)), "bn_fwd_t")
         return dm.get(), dv.get(), self.get_t(dy, a_dt)
 
+    def stem_fwd_bf16(self, x, w):
+        N, _, H, _ = x.shape
+        dx, dw, dy = self.dev(x), self.dev(w), self.dev(shape=(N, 64, H // 2, H // 2))
+        self._chk(self.L.mi_op_stem_fwd_bf16(dx.ptr, dw.ptr, dy.ptr, N, H), "stem_fwd_bf16")
+        return dy.get()
+
+    def stem_wgrad_bf16(self, x, w, dy):
+        N, _, H, _ = x.shape
+        dx, dw, ddy, out = self.dev(x), self.dev(w), self.dev(dy), self.dev(shape=w.shape)
+        self._chk(self.L.mi_op_stem_wgrad_bf16(dx.ptr, dw.ptr, ddy.ptr, out.ptr, N, H), "stem_wgrad_bf16")
+        return out.get()
+
     def conv_bn_fwd_t(self, x, w, gamma, beta, stride, eps, relu, dt):
         """conv + BN as forward_pass pairs them; returns conv_out, means, vars, y and whether the statistics were fused"""
         N, Cc, H, _ = x.shape

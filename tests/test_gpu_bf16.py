@@ -157,6 +157,20 @@ def test_conv_bn_pair_statistics_from_the_conv_epilogue(ops, oracle, shape, dt):
         assert rel_l2(nhwc(gy), act) <= 2e-5
 
 
+@pytest.mark.parametrize("H,N", [(224, 2), (32, 4), (64, 3), (96, 1)])
+def test_stem_bf16(ops, oracle, H, N):
+    """the 7x7 stride-2 stem on the bf16 matrix cores: image and weights rounded to bf16, fp32 accumulation, fp32 tensors"""
+    x = rand((N, H, H, 3), 11)
+    w = rand((64, 3, 7, 7), 12, scale=(2.0 / (49 * 67)) ** 0.5)
+    dy = rand((N, H // 2, H // 2, 64), 13)
+    ref = oracle.conv_fwd(bf16_round(x), bf16_round(w), 2)
+    got = ops.stem_fwd_bf16(nchw(x), w)
+    assert rel_l2(nhwc(got), ref) <= 1e-5, rel_l2(nhwc(got), ref)
+    ref_dw = oracle.conv_wgrad(bf16_round(x), bf16_round(dy), 7, 2)
+    got_dw = ops.stem_wgrad_bf16(nchw(x), w, nchw(dy))
+    check_grad(got_dw, ref_dw, "stem wgrad (bf16 operands)")
+
+
 def test_bf16_kernels_refuse_shapes_that_do_not_tile(ops):
     x, w = rand((2, 3, 32, 32), 1), rand((64, 3, 7, 7), 2)
     assert ops.L.mi_bf16_conv_supported(0, 2, 3, 32, 64, 7, 2) == 0

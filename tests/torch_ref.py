@@ -127,8 +127,9 @@ class TorchNetBF16(TorchNet):
     def _unit(self, x, i, K, C, k, stride, relu, name, residual=None):
         w = self.p[i].view(K, C, k, k)
         stem = name == "stem"
-        if not stem:
-            w = w + (_rb(w.detach()) - w.detach())  # rounded value, gradient to the fp32 master copy
+        w = w + (_rb(w.detach()) - w.detach())  # rounded value, gradient to the fp32 master copy
+        if stem:  # the stem multiplies the bf16-rounded image (kernels_stem_bf16.hip); its output stays an fp32 tensor.  (Its weight
+            x = _rb(x)  # gradient also rounds dY on the way in: 2^-9 relative noise per element, averaged over 10^5..10^6 terms)
         y = F.conv2d(x, w, stride=stride, padding=k // 2)
         if not stem:
             y = _RoundBF16.apply(y)
