@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0
 FAMILIES_F32 = {0: "direct conv 7x7 stem / untiled 3x3 fwd+dgrad (dconv_kernel, VALU)", 1: "direct conv wgrad (wgradC/wgrad_kernel, VALU)",
                 2: "1x1 conv / FC GEMM (igemm_kernel<*,1,1,*> / gemm_mfma_kernel, fp32 MFMA)", 3: "batch norm fwd+bwd",
                 5: "3x3 conv fwd+dgrad+wgrad incl. the 3x3-s2 projections (igemm_kernel<*,3,*,*>, implicit GEMM on fp32 MFMA)"}
-FAMILIES_BF16 = {0: "7x7 stem fwd (dconv_kernel, fp32 VALU)", 1: "7x7 stem wgrad (wgrad_kernel, fp32 VALU)",
+FAMILIES_BF16 = {0: "7x7 stem fwd (st_pad + st_fwd_kernel, bf16 MFMA, fp32 output)", 1: "7x7 stem wgrad (st_wgrad_kernel, bf16 MFMA, fp32 dY)",
                  2: "1x1 conv (bgemm_kernel<*,1,1,*>, bf16 MFMA) + FC GEMM (fp32 MFMA)", 3: "batch norm fwd+bwd (bf16 tensors, fp32 math)",
                  5: "3x3 conv fwd+dgrad+wgrad incl. the 3x3-s2 projections (bgemm_kernel<*,3,*,*>, implicit GEMM on bf16 MFMA)"}
 PMC_KEY = {0: "dconv", 1: "wgradC", 2: "gemm", 3: "bn", 5: "igemm3x3"}
@@ -192,11 +192,21 @@ def main():
     timings = tr.timings()
 
     fam_stats, dt_fam, dt_h2d = {}, None, None
+    fam_serial, dt_serial = {}, None
     if prof and not args.no_extra:
         lib.mi_prof_enable(1)
         lib.mi_prof_reset()
         dt_fam, _ = timed(args.steps)   # K further steps, every launch of every family bracketed
         fam_stats = read_prof()
+        if not bf16 and world == 1:
+            # ... and K more in the SERIAL schedule: in the default one the weight gradients run on a second stream beside the
+            # next layer's BN', so a family's bracketed time there includes what it lost to its neighbour (HBM-bound next to
+            # MFMA-bound: both slow down, the step gains ~1 %); this is the family on its own
+            lib.mi_trainer_set_overlap(tr.t, 0)
+            tr.step()
+            lib.mi_prof_reset()
+            dt_serial, _ = timed(args.steps)
+            fam_serial = read_prof()
     lib.mi_prof_enable(0)
     if not args.no_extra and world == 1:
         # K further steps with the reference's own data movement: the batch sits in pinned host memory and is copied over
@@ -235,7 +245,7 @@ def main():
             sec = max(ms, 1e-9) * 1e-3
             tf, gbs = fl / sec / 1e12, by / sec / 1e9
             # which roof binds the family: its arithmetic intensity against the machine balance of the pipe it runs on
-            peak_tf = BF16_PEAK_TFLOPS if (bf16 and fam in (2, 5)) else FP32_PEAK_TFLOPS
+            peak_tf = BF16_PEAK_TFLOPS if (bf16 and fam in (0, 1, 2, 5)) else FP32_PEAK_TFLOPS
             mfma_bound = fl > 0 and (fl / max(by, 1.0)) >= peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
             r = {"kernel": FAMILIES[fam], "bound": "mfma" if mfma_bound else "hbm", "launches_per_step": round(n / steps, 1),
                  "ms_per_step": round(ms / steps, 3)}
@@ -270,6 +280,11 @@ def main():
                             "`achieved` = algorithmic work of the family's launches / their HIP-event durations inside the timed region")
             if fam_stats:
                 roof["families"] = [roof_of(f, fam_stats[f], args.steps) for f in sorted(fam_stats) if fam_stats[f][0] > 0]
+                if fam_serial:
+                    roof["families_serial_schedule"] = [roof_of(f, fam_serial[f], args.steps) for f in sorted(fam_serial) if fam_serial[f][0] > 0]
+                    roof["families_serial_note"] = ("%d further steps with mi_trainer_set_overlap(0) (weight gradients on the compute stream, nothing runs "
+                                                    "beside anything): %.3f ms/step; the default schedule is the faster STEP, the serial one shows each "
+                                                    "family undisturbed" % (args.steps, dt_serial / args.steps * 1e3))
                 roof["families_note"] = ("%d further steps with every launch of every family bracketed by HIP events: %.3f ms/step "
                                          "(weight gradients run on a second stream next to batch norm, so family times overlap and do not add up to the step)"
                                          % (args.steps, dt_fam / args.steps * 1e3))

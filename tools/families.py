@@ -9,3 +9,5 @@ for l in open(sys.argv[1]):
     print('  DOM %-60s %7.3f ms %8.1f %s frac %.3f'%(r['kernel'][:60], r['ms_per_step'], r['achieved'], r['unit'], r['frac']))
     for f in r.get('families',[]):
         print('      %-60s %7.3f ms %8.1f %s frac %.3f'%(f['kernel'][:60], f['ms_per_step'], f['achieved'], f['unit'], f['frac']))
+    for f in r.get('families_serial_schedule',[]):
+        print('   SER %-60s %7.3f ms %8.1f %s frac %.3f'%(f['kernel'][:60], f['ms_per_step'], f['achieved'], f['unit'], f['frac']))
