@@ -377,6 +377,13 @@ int mi_op_conv_fwd_bf16(const void *x_bf16, const float *w_kcrs, void *y_bf16, i
 int mi_op_conv_dgrad_bf16(const float *w_kcrs, const void *dy_bf16, void *dx_bf16, int N, int C, int H, int K, int k, int stride,
                           int to_add);
 int mi_op_conv_wgrad_bf16(const void *x_bf16, const void *dy_bf16, float *dw_kcrs, int N, int C, int H, int K, int k, int stride);
+/* prepreAndDoConvolutionDeriv + activationAndBatchNormDeriv as backwards_pass chains them in bf16 storage (resnet.cu:1399-1429,
+ * 1455-1480): dgrad of a convolution, then the backward of the batch norm (+ReLU, gate = mask > 0) in front of it; where the launch
+ * allows the dgrad does the BN' reduction pass in its epilogue.  gated = (mask > 0 ? dgrad(+addend) : 0), bn_dx = the BN's input
+ * gradient.  Image tensors bf16.  Returns < 0 on error, else the number of partial rows the dgrad left (0 = separate pass). */
+int mi_op_conv_dgrad_bn_bwd_bf16(const float *w_kcrs, const void *dy, const void *addend, void *gated, int N, int C, int H, int K, int k,
+                                 int stride, const void *bn_x, const void *mask, const float *gamma, const float *beta, const float *means,
+                                 const float *vars, float eps, void *bn_dx, float *dgamma, float *dbeta);
 /* the stem convolution of the bf16 storage mode (7x7 stride 2, 3 -> 64 filters, H a multiple of 32; doConvolution /
  * convolutionDerivWeights, resnet.cu:109-156, 227-281): fp32 tensors in and out, image and weights rounded to bf16 inside,
  * fp32 accumulation on the bf16 matrix cores.  -2: shape not covered (the trainer then keeps the fp32 stem). */

@@ -292,6 +292,45 @@ bn_bwd_reduce_kernel(const TX *__restrict__ x, const TA *__restrict__ dy, const 
     }
 }
 
+// The reduction pass done by the dgrad that produced dy (kernels_igemm_bf16.hip: two planes [np][C] of sum g and sum g (x - mean)
+// per column tile): -> the (channel, split) table bn_bwd_finalize_kernel reads, s2 divided by sd = sqrt(var + eps).
+// grid (ceil(C / 64), G): a workgroup adds one chunk of the np partials for 64 channels, eight in flight per thread, fixed order.
+__global__ void __launch_bounds__(256)
+bn_bwd_parts_merge_kernel(const float *__restrict__ parts, int np, int C, const float *__restrict__ vars, float eps, float *__restrict__ partial) {
+    const int cx = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const int chunk = (np + gridDim.y - 1) / gridDim.y;
+    const int p0 = blockIdx.y * chunk, p1 = min(np, p0 + chunk);
+    const size_t plane = (size_t)np * C;
+    float a1 = 0.f, a2 = 0.f;
+    if (c < C) {
+        int p = p0 + sg;
+        for (; p + 7 * 4 < p1; p += 8 * 4) {
+            float u1[8], u2[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const size_t o = (size_t)(p + 4 * u) * C + c;
+                u1[u] = parts[o]; u2[u] = parts[plane + o];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { a1 += u1[u]; a2 += u2[u]; }
+        }
+        for (; p < p1; p += 4) {
+            const size_t o = (size_t)p * C + c;
+            a1 += parts[o]; a2 += parts[plane + o];
+        }
+    }
+    __shared__ float sh[2][4][64];
+    sh[0][sg][cx] = a1; sh[1][sg][cx] = a2;
+    __syncthreads();
+    if (sg == 0 && c < C) {
+        const float s1 = (sh[0][0][cx] + sh[0][1][cx]) + (sh[0][2][cx] + sh[0][3][cx]);
+        const float s2 = (sh[1][0][cx] + sh[1][1][cx]) + (sh[1][2][cx] + sh[1][3][cx]);
+        float *o = partial + ((size_t)c * BN_SPLIT_MAX + blockIdx.y) * 3;
+        o[0] = s1; o[1] = s2 / sqrtf(vars[c] + eps);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 bn_bwd_finalize_kernel(float *__restrict__ partial, int nsplit, int C, float *__restrict__ dgamma, float *__restrict__ dbeta) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63; // one wave per channel, lane = split
@@ -507,19 +546,25 @@ int mid_bn_fwd_parts(mid_stream s, float *ws, const mid_bn_parts *parts, const f
     return mid_bn_fwd_t(s, ws, parts, x, MID_F32, gamma, beta, residual, means, vars, y, MID_F32, xhat_out, norm_out, N, C, P, eps, relu);
 }
 
+// bparts != NULL (nparts > 0): the reduction pass was done by the dgrad that produced dy (which is already gated: mask_mode 0)
 static int bn_bwd_impl(hipStream_t st, float *ws, const void *x, int x_dt, const float *gamma, const float *beta, const float *means,
                        const float *vars, const void *dy, const void *mask_src, void *gated_out, int a_dt, void *dx, float *dgamma,
-                       float *dbeta, int N, int C, int P, float eps, int mask_mode) {
+                       float *dbeta, int N, int C, int P, float eps, int mask_mode, const mid_bn_bwd_parts *bparts = nullptr) {
     if (!bn_pair_ok(x_dt, a_dt)) { mi_record_error("mid_bn_bwd", "unsupported storage types"); return -2; }
-    const int ns = bn_nsplit(N, C);
+    int ns = bn_nsplit(N, C);
     dim3 grid(C, ns), block(256);
     if (mask_mode >= 2 && !mask_src) { mi_record_error("mid_bn_bwd", "mask_src missing"); return -2; }
     if (mask_mode == 3 && !gated_out) { mi_record_error("mid_bn_bwd_gate", "gated_out missing"); return -2; }
     // passes over N*C*P elements: reduce reads x, dy (+mask) (+writes gated); apply reads x, dy (+mask) | x, gated; writes dx
     const double xb = (double)N * C * P * dt_bytes(x_dt), ab = (double)N * C * P * dt_bytes(a_dt);
-    mi_prof_begin(st, MI_FAM_BN, 0.0, 3 * xb + ab * (mask_mode >= 2 ? 4 : 2));
+    mi_prof_begin(st, MI_FAM_BN, 0.0, bparts ? 2 * xb + ab : 3 * xb + ab * (mask_mode >= 2 ? 4 : 2));
     const int vec = bn_vec(x_dt, a_dt, P);
     const FastDiv fdPV = make_fastdiv(P / vec);
+    if (bparts) {
+        ns = bparts->nparts >= 64 * 8 ? 64 : bparts->nparts >= 64 ? 8 : 1;
+        hipLaunchKernelGGL(bn_bwd_parts_merge_kernel, dim3(mi_cdiv(C, 64), ns), dim3(256), 0, st, bparts->buf, bparts->nparts, C, vars, eps, ws);
+        MI_LAUNCH_CHECK("bn_bwd_parts_merge_kernel");
+    } else {
 #define BWD_REDUCE_M(M_, TX, TA, V)                                                                                         \
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<M_, TX, TA, V>), grid, block, 0, st, (const TX *)x, (const TA *)dy, (const TA *)mask_src, \
                        gamma, beta, means, vars, ws, (TA *)gated_out, N, C, P, eps, fdPV)
@@ -537,6 +582,7 @@ static int bn_bwd_impl(hipStream_t st, float *ws, const void *x, int x_dt, const
 #undef BWD_R3
 #undef BWD_REDUCE_M
     MI_LAUNCH_CHECK("bn_bwd_reduce_kernel");
+    }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(mi_cdiv(C, 4)), dim3(256), 0, st, ws, ns, C, dgamma, dbeta);
     MI_LAUNCH_CHECK("bn_bwd_finalize_kernel");
     const size_t total = (size_t)N * C * P;
@@ -578,6 +624,12 @@ int mid_bn_bwd_t(mid_stream s, float *ws, const void *x, int x_dt, const float *
                  float *dbeta, int N, int C, int P, float eps, int mask_mode) {
     if (mask_mode < 0 || mask_mode > 3) { mi_record_error("mid_bn_bwd", "mask_mode"); return -2; }
     return bn_bwd_impl((hipStream_t)s, ws, x, x_dt, gamma, beta, means, vars, dy, mask_src, gated_out, a_dt, dx, dgamma, dbeta, N, C, P, eps, mask_mode);
+}
+int mid_bn_bwd_parts_t(mid_stream s, float *ws, const mid_bn_bwd_parts *parts, const void *x, int x_dt, const float *gamma, const float *beta,
+                       const float *means, const float *vars, const void *dy_gated, int a_dt, void *dx, float *dgamma, float *dbeta, int N,
+                       int C, int P, float eps) {
+    if (!parts || parts->nparts <= 0) { mi_record_error("mid_bn_bwd_parts_t", "no partials"); return -2; }
+    return bn_bwd_impl((hipStream_t)s, ws, x, x_dt, gamma, beta, means, vars, dy_gated, nullptr, nullptr, a_dt, dx, dgamma, dbeta, N, C, P, eps, 0, parts);
 }
 int mid_bn_bwd(mid_stream s, float *ws, const float *x, const float *gamma, const float *beta, const float *means,
                const float *vars, const float *dy, const float *mask_src, float *dx, float *dgamma, float *dbeta, int N,

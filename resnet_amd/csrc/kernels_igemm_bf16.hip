@@ -55,6 +55,12 @@ struct BgArgs {
     float *bn_part;            // forward: statistics partials, three planes [bn_np][K]
     int bn_np;
     int vw;                    // fwd / dgrad-s1 epilogue: pixels per store (8, 4 or 1)
+    // dgrad (pixel-major epilogue) that also does the REDUCTION pass of the batch-norm backward its output feeds: the stored
+    // gradient is gated by bnb_mask > 0, and per (column tile, channel) the sums of g and g (x - mean) go to bnb_part
+    const u16 *bnb_x, *bnb_mask;
+    const float *bnb_mean;
+    float *bnb_part;           // two planes [bnb_np][C]
+    int bnb_np;
 };
 
 __device__ __forceinline__ float bg_bf2f(u16 v) { return __uint_as_float((uint32_t)v << 16); }
@@ -611,6 +617,42 @@ bgemm_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Bop, void *__r
                     }
 #pragma unroll
                     for (int e = 0; e < CPX / 2; e++) pk[e] = bg_pack2(w[2 * e], w[2 * e + 1]);
+                    if (g.bnb_part) { // (uniform) the BN' reduction over this wave's WNC pixels of channel `row`
+                        const int ch = m0 + wm * 64 + ch0 + row;
+                        const float mean = g.bnb_mean[ch];
+                        float s1 = 0.f, s2 = 0.f;
+                        if (ok) {
+                            uint32_t xv[CPX / 2], mv[CPX / 2];
+                            if constexpr (CPX == 8) {
+                                const u32x4 x4 = *(const u32x4 *)(g.bnb_x + o), m4 = *(const u32x4 *)(g.bnb_mask + o);
+#pragma unroll
+                                for (int e = 0; e < 4; e++) { xv[e] = x4[e]; mv[e] = m4[e]; }
+                            } else {
+                                const u32x2 x2 = *(const u32x2 *)(g.bnb_x + o), m2 = *(const u32x2 *)(g.bnb_mask + o);
+#pragma unroll
+                                for (int e = 0; e < 2; e++) { xv[e] = x2[e]; mv[e] = m2[e]; }
+                            }
+#pragma unroll
+                            for (int e = 0; e < CPX / 2; e++) {
+                                // the gradient as it is STORED (rounded), gated by the sign of the activation; bf16 > 0 <=> its 16 bits
+                                // as a signed integer > 0 (NaN aside)
+                                const bool on0 = (int16_t)(mv[e] & 0xffffu) > 0, on1 = (int32_t)mv[e] > 0xffff;
+                                const float g0 = on0 ? __uint_as_float(pk[e] << 16) : 0.f, g1 = on1 ? __uint_as_float(pk[e] & 0xffff0000u) : 0.f;
+                                pk[e] = (on0 ? pk[e] & 0xffffu : 0u) | (on1 ? pk[e] & 0xffff0000u : 0u);
+                                s1 += g0 + g1;
+                                s2 = fmaf(g0, __uint_as_float(xv[e] << 16) - mean, s2);
+                                s2 = fmaf(g1, __uint_as_float(xv[e] & 0xffff0000u) - mean, s2);
+                            }
+                        }
+#pragma unroll
+                        for (int m = 1; m < CPR; m <<= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+                        if (c == 0) {
+                            constexpr int PPT = 4 / WMW;
+                            const size_t po = (size_t)(ct * PPT + wn) * Mdim + ch;
+                            g.bnb_part[po] = s1;
+                            g.bnb_part[(size_t)g.bnb_np * Mdim + po] = s2;
+                        }
+                    }
                 } else {
                     if constexpr (CPX == 8) { const u32x4 v = *(const u32x4 *)sp; pk[0] = v[0]; pk[1] = v[1]; pk[2] = v[2]; pk[3] = v[3]; }
                     else { const u32x2 v = *(const u32x2 *)sp; pk[0] = v[0]; pk[1] = v[1]; }
@@ -1057,11 +1099,15 @@ static int bgemm_single_buffer(int tiles, int ks) {
     const double t3 = (double)((tiles + 767) / 768) * 3.0 / gain;
     return t3 < t2;
 }
+static int bgemm_swp_enabled(void) {
+    static int swp_on = -1;
+    if (swp_on < 0) { const char *e = getenv("RESNET_MI_BF16_SWP"); swp_on = e ? atoi(e) : 1; }
+    return swp_on;
+}
 template <int MODE, int KS, int S>
 static int bgemm_launch_v(hipStream_t st, dim3 grid, const u16 *A, const u16 *B, void *out, const u16 *addend, const BgArgs &g, int bm, int vw) {
     // the pixel-major product (SWP): 16-byte staging, planes a multiple of 4 pixels, contiguous output pixels
-    static int swp_on = -1;
-    if (swp_on < 0) { const char *e = getenv("RESNET_MI_BF16_SWP"); swp_on = e ? atoi(e) : 1; }
+    const int swp_on = bgemm_swp_enabled();
     if constexpr (MODE != BG_WGRAD && !(MODE == BG_DGRAD && S == 2)) {
         if (vw == 8 && g.vw > 1 && swp_on) {
             if (bgemm_single_buffer(g.tiles, KS)) {
@@ -1171,8 +1217,11 @@ int mi_bgemm_fwd(hipStream_t st, mid_workspace *ws, const u16 *x, const float *w
     return 0;
 }
 
+// fz (optional): the reduction pass of the batch-norm backward that consumes dx, fused into this kernel's epilogue where the
+// launch takes the pixel-major form; fz->nparts > 0 on return says it did (dx then holds the GATED gradient)
 int mi_bgemm_dgrad(hipStream_t st, mid_workspace *ws, const float *w, const u16 *dy, u16 *dx, const u16 *addend, int N, int C, int H,
-                   int K, int k, int stride) {
+                   int K, int k, int stride, mid_bn_bwd_parts *fz) {
+    if (fz) fz->nparts = 0;
     const int T = k * k;
     const u16 *A = (const u16 *)ws->pre_dgrad;
     if (!A) {
@@ -1190,8 +1239,15 @@ int mi_bgemm_dgrad(hipStream_t st, mid_workspace *ws, const float *w, const u16 
     g.tiles = g.mtiles * ctl;
     g.fdM = make_fastdiv(g.mtiles);
     g.vw = bgemm_vw(g.HW);
+    if (fz && fz->buf && stride == 1 && svw == 8 && g.vw > 1 && bgemm_swp_enabled()) {
+        const int np = ctl * (bm == 128 ? 2 : 4);
+        if (fz->floats >= (size_t)2 * np * C) {
+            g.bnb_x = (const u16 *)fz->x; g.bnb_mask = (const u16 *)fz->mask; g.bnb_mean = fz->means;
+            g.bnb_part = fz->buf; g.bnb_np = np; fz->nparts = np;
+        }
+    }
     mi_prof_begin(st, bgemm_fam(k), 2.0 * T * (double)N * g.P * C * K,
-                  2.0 * ((double)N * g.P * K + (double)N * C * g.HW * (addend ? 2 : 1)) + 4.0 * T * C * K);
+                  2.0 * ((double)N * g.P * K + (double)N * C * g.HW * ((addend ? 2 : 1) + (g.bnb_part ? 2 : 0))) + 4.0 * T * C * K);
     const int rc = bgemm_launch<BG_DGRAD>(st, dim3(g.tiles, stride == 2 ? 4 : 1), A, dy, dx, addend, g, k, stride, bm, svw);
     mi_prof_end(st);
     if (rc) return rc;
@@ -1276,7 +1332,12 @@ int mid_conv_fwd_bf16(mid_stream s, mid_workspace *ws, const void *x, const floa
 int mid_conv_dgrad_bf16(mid_stream s, mid_workspace *ws, const float *w, const void *dy, void *dx, const void *addend, int N, int C,
                         int H, int K, int k, int stride) {
     if (!mi_bgemm_supported(BGOP_DGRAD, N, C, H, K, k, stride)) { mi_record_error("mid_conv_dgrad_bf16", "shape not supported by the bf16 kernels"); return -2; }
-    return mi_bgemm_dgrad((hipStream_t)s, ws, w, (const u16 *)dy, (u16 *)dx, (const u16 *)addend, N, C, H, K, k, stride);
+    return mi_bgemm_dgrad((hipStream_t)s, ws, w, (const u16 *)dy, (u16 *)dx, (const u16 *)addend, N, C, H, K, k, stride, nullptr);
+}
+int mid_conv_dgrad_bn_bf16(mid_stream s, mid_workspace *ws, const float *w, const void *dy, void *dx, const void *addend, int N, int C,
+                           int H, int K, int k, int stride, mid_bn_bwd_parts *fz) {
+    if (!mi_bgemm_supported(BGOP_DGRAD, N, C, H, K, k, stride)) { mi_record_error("mid_conv_dgrad_bn_bf16", "shape not supported by the bf16 kernels"); return -2; }
+    return mi_bgemm_dgrad((hipStream_t)s, ws, w, (const u16 *)dy, (u16 *)dx, (const u16 *)addend, N, C, H, K, k, stride, fz);
 }
 int mid_conv_wgrad_bf16(mid_stream s, mid_workspace *ws, const void *x, const void *dy, float *dw, int N, int C, int H, int K, int k,
                         int stride) {

@@ -112,6 +112,23 @@ size_t mid_bf16_part_floats(int N, int C, int H, int K, int k, int stride);
 int mid_conv_prelayout_all_bf16(mid_stream s, const mid_wt_entry *entries_dev, const int *tile_entry_dev, int ntiles);
 int mid_conv_fwd_bf16(mid_stream s, mid_workspace *ws, const void *x, const float *w, void *y, int N, int C, int H, int K, int k,
                       int stride, mid_bn_parts *parts);
+/* The REDUCTION pass of a batch-norm backward fused into the dgrad that produces its dy (bf16 kernels, pixel-major epilogue):
+ * the dgrad stores g = (mask > 0 ? dx : 0) instead of dx and leaves per-tile sums of g and g (x - mean) per channel in buf (two
+ * planes [nparts][C]); nparts comes back > 0 when the launch could do it.  mid_bn_bwd_parts_t then finishes that batch norm
+ * (merge, finalize, apply) without reading dy for the sums. */
+typedef struct {
+    const void *x;       /* the BN's input (the convolution output it normalised), bf16, the shape of the dgrad output */
+    const void *mask;    /* the tensor whose sign gates: that BN's activated output, or the block output for the expansion BN */
+    const float *means;
+    float *buf;
+    size_t floats;
+    int nparts;
+} mid_bn_bwd_parts;
+int mid_conv_dgrad_bn_bf16(mid_stream s, mid_workspace *ws, const float *w, const void *dy, void *dx, const void *addend, int N, int C,
+                           int H, int K, int k, int stride, mid_bn_bwd_parts *fz);
+int mid_bn_bwd_parts_t(mid_stream s, float *stats_ws, const mid_bn_bwd_parts *parts, const void *x, int x_dt, const float *gamma,
+                       const float *beta, const float *means, const float *vars, const void *dy_gated, int a_dt, void *dx, float *dgamma,
+                       float *dbeta, int N, int C, int P, float eps);
 int mid_conv_dgrad_bf16(mid_stream s, mid_workspace *ws, const float *w, const void *dy, void *dx, const void *addend, int N, int C,
                         int H, int K, int k, int stride);
 int mid_conv_wgrad_bf16(mid_stream s, mid_workspace *ws, const void *x, const void *dy, float *dw, int N, int C, int H, int K, int k,

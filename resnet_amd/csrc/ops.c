@@ -139,6 +139,37 @@ int mi_op_conv_wgrad_bf16(const void *x, const void *dy, float *dw, int N, int C
     ws_free(&ws);
     return rc;
 }
+/* dgrad of one convolution followed by the backward of the batch norm (+ReLU) in front of it, the way backwards_pass chains them in
+ * bf16 storage (prepreAndDoConvolutionDeriv + activationAndBatchNormDeriv, resnet.cu:1399-1429, 1455-1480): where the launch allows, the
+ * dgrad gates its output by mask > 0 and does the BN' reduction pass in its epilogue.  All image tensors bf16.
+ * Returns < 0 on error, else the number of partial rows the dgrad left (0 = the separate reduction pass ran). */
+int mi_op_conv_dgrad_bn_bwd_bf16(const float *w, const void *dy, const void *addend, void *gated, int N, int C, int H, int K, int k, int stride,
+                                 const void *bn_x, const void *mask, const float *gamma, const float *beta, const float *means,
+                                 const float *vars, float eps, void *bn_dx, float *dgamma, float *dbeta) {
+    mid_workspace ws;
+    if (ws_make(&ws, (size_t)k * k * C * K, 0)) return -3;
+    mid_bn_bwd_parts fz = {bn_x, mask, means, NULL, mid_bn_parts_floats(N, C, H), 0};
+    fz.buf = (float *)mid_malloc(fz.floats * sizeof(float));
+    float *bws = (float *)mid_malloc(mid_bn_ws_floats(C) * sizeof(float));
+    if (addend) mid_memcpy_d2d(gated, addend, (size_t)N * C * H * H * 2, mi_global()->compute);
+    int rc = mid_conv_dgrad_bn_bf16(mi_global()->compute, &ws, w, dy, gated, addend ? gated : NULL, N, C, H, K, k, stride, &fz);
+    if (!rc) {
+        if (fz.nparts > 0)
+            rc = mid_bn_bwd_parts_t(mi_global()->compute, bws, &fz, bn_x, MID_BF16, gamma, beta, means, vars, gated, MID_BF16, bn_dx, dgamma, dbeta, N, C, H * H, eps);
+        else { /* the unfused chain: BN' gates by the mask itself (mode 3 writes the gated gradient where the fused form leaves it) */
+            void *tmp = mi_malloc((size_t)N * C * H * H * 2);
+            rc = mid_bn_bwd_t(mi_global()->compute, bws, bn_x, MID_BF16, gamma, beta, means, vars, gated, mask, tmp, MID_BF16, bn_dx, dgamma, dbeta, N, C, H * H, eps, 3);
+            if (!rc) mid_memcpy_d2d(gated, tmp, (size_t)N * C * H * H * 2, mi_global()->compute);
+            rc = finish(rc);
+            mi_free(tmp);
+        }
+    }
+    rc = finish(rc);
+    mid_free(bws);
+    mid_free(fz.buf);
+    ws_free(&ws);
+    return rc < 0 ? rc : fz.nparts;
+}
 /* the bf16-mode stem (7x7 stride 2, 3 -> 64): x, y, dy fp32 tensors; image and weights rounded to bf16 inside */
 int mi_op_stem_fwd_bf16(const float *x, const float *w, float *y, int N, int H) {
     if (!mid_stem_bf16_supported(3, H, 64, 7, 2)) return -2;

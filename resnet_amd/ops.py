@@ -231,6 +231,23 @@ class Ops:
                                         int(relu)), "bn_fwd_t")
         return dm.get(), dv.get(), self.get_t(dy, a_dt)
 
+    def conv_dgrad_bn_bwd_bf16(self, w, dy, H, stride, bn_x, mask, gamma, beta, means, vars_, eps, addend=None):
+        """dgrad + the BN(+ReLU) backward in front of it, chained as backwards_pass does; returns gated dy, bn dx, dgamma, dbeta, fused?"""
+        N = dy.shape[0]
+        K, Cc, k, _ = w.shape
+        BF = B.MI_DTYPE_BF16
+        dw, ddy = self.dev(w), self.dev_t(dy, BF)
+        dadd = self.dev_t(addend, BF) if addend is not None else None
+        dxb, dmask = self.dev_t(bn_x, BF), self.dev_t(mask, BF)
+        dg, db, dm, dv = (self.dev(a) for a in (gamma, beta, means, vars_))
+        gated, bdx = self.new_t((N, Cc, H, H), BF), self.new_t((N, Cc, H, H), BF)
+        og, ob = self.dev(shape=(Cc,)), self.dev(shape=(Cc,))
+        rc = self.L.mi_op_conv_dgrad_bn_bwd_bf16(dw.ptr, ddy.ptr, dadd.ptr if dadd else None, gated.ptr, N, Cc, H, K, k, stride, dxb.ptr, dmask.ptr,
+                                                 dg.ptr, db.ptr, dm.ptr, dv.ptr, eps, bdx.ptr, og.ptr, ob.ptr)
+        if rc < 0:
+            self._chk(rc, "conv_dgrad_bn_bwd_bf16")
+        return self.get_t(gated, BF), self.get_t(bdx, BF), og.get(), ob.get(), rc > 0
+
     def stem_fwd_bf16(self, x, w):
         N, _, H, _ = x.shape
         dx, dw, dy = self.dev(x), self.dev(w), self.dev(shape=(N, 64, H // 2, H // 2))

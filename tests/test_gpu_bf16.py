@@ -157,6 +157,46 @@ def test_conv_bn_pair_statistics_from_the_conv_epilogue(ops, oracle, shape, dt):
         assert rel_l2(nhwc(gy), act) <= 2e-5
 
 
+# dgrad + the BN(+ReLU) backward it feeds, chained as backwards_pass does: (C, H, K, k, stride, N) of the convolution whose dgrad runs;
+# the batch norm is the one in front of it (C channels at H x H)
+DGRAD_BN_SHAPES = [
+    (64, 56, 256, 1, 1, 2),      # expansion dgrad -> spatial BN' (64-row tiles)
+    (64, 56, 64, 3, 1, 2),       # spatial dgrad -> reduction BN'
+    (256, 56, 64, 1, 1, 2),      # next block's reduction dgrad (+ addend) -> this block's expansion BN' (gate = block output)
+    (128, 28, 512, 1, 1, 3),
+    (512, 28, 128, 1, 1, 2),
+    (256, 14, 256, 3, 1, 3),     # P = 196: 8-byte epilogue
+    (1024, 14, 256, 1, 1, 3),
+    (512, 7, 512, 3, 1, 5),      # 7x7 planes: not fused (channel-major epilogue), the separate reduction pass runs
+    (128, 56, 128, 3, 2, 2),     # stride-2 dgrad: not fused
+    (64, 10, 64, 1, 1, 3),       # ragged: 300 columns
+]
+
+
+@pytest.mark.parametrize("shape", DGRAD_BN_SHAPES, ids=["C%d_H%d_K%d_k%d_s%d_N%d" % s for s in DGRAD_BN_SHAPES])
+@pytest.mark.parametrize("with_addend", [0, 1])
+def test_dgrad_with_the_bn_backward_reduction_in_its_epilogue(ops, oracle, shape, with_addend):
+    C, H, K, k, stride, N = shape
+    eps = 1e-7
+    _, w, dy = _conv_data(*shape)
+    bn_x = bf16_round(rand((N, H, H, C), 21, 1.5) + 0.3)             # the convolution output the batch norm normalised
+    gamma = (1 + 0.2 * rand((C,), 22)).astype(np.float32)
+    beta = (0.3 * rand((C,), 23)).astype(np.float32)
+    means, vars_, xhat, norm, act = oracle.bn_fwd(bn_x, gamma, beta, eps, 1)
+    mask = bf16_round(act)                                            # its activated output gates
+    addend = bf16_round(rand((N, H, H, C), 24)) if with_addend else None
+    ref_d = oracle.conv_dgrad(bf16_round(w), dy, H, stride, dx_init=addend) if with_addend else oracle.conv_dgrad(bf16_round(w), dy, H, stride)
+    ref_g = np.where(mask > 0, bf16_round(ref_d), 0).astype(np.float32)
+    rdx, rdg, rdb = oracle.bn_bwd(bn_x, gamma, eps, means, vars_, xhat, mask, ref_g, 0)   # dy already gated
+    gated, bdx, dg, db, fused = ops.conv_dgrad_bn_bwd_bf16(w, nchw(dy), H, stride, nchw(bn_x), nchw(mask), gamma, beta, means, vars_, eps,
+                                                           addend=nchw(addend) if with_addend else None)
+    assert fused == (stride == 1 and (H * H) % 4 == 0), "which launches fuse"
+    check_bf(nhwc(gated), ref_g, "gated dgrad %s" % (shape,))
+    check_grad(db, rdb, "dbeta", rel=2e-3)      # sums of bf16-rounded gradients whose last bit may differ from the oracle's rounding
+    check_grad(dg, rdg, "dgamma", rel=2e-3)
+    check_bf(nhwc(bdx), rdx, "bn dx")
+
+
 @pytest.mark.parametrize("H,N", [(224, 2), (32, 4), (64, 3), (96, 1)])
 def test_stem_bf16(ops, oracle, H, N):
     """the 7x7 stride-2 stem on the bf16 matrix cores: image and weights rounded to bf16, fp32 accumulation, fp32 tensors"""
