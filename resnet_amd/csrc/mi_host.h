@@ -64,6 +64,10 @@ typedef struct MiCtx {
     size_t act_bytes, dev_bytes; /* forward activations kept for backward / every tracked allocation */
     size_t *alloc_bytes;
     float *rc_buf[2];            /* RECOMPUTE_BN: scratch for the BN(+ReLU) tensors (forward: consumed at once; backward: re-derived) */
+    /* bf16: the reduction pass of a unit's BN' done by the dgrad that produces its dy (mid_conv_dgrad_bn_bf16).  backwards_pass
+     * fills fz_req before the unit whose dgrad should do it; the unit's dgrad moves it to fz_done (nparts > 0) for the next unit_bwd */
+    mid_bn_bwd_parts fz_req, fz_done;
+    int fz_req_valid, fz_ready, fz_enable;
     float *stem_dx;              /* bf16 mode: the stem convolution's output gradient stays fp32 */
     void *stem_xp; size_t stem_xp_bytes;           /* bf16 mode: the batch as zero-padded bf16 parity planes (kernels_stem_bf16.hip) */
     float *stem_scratch; size_t stem_scratch_floats; /*            its wave partials + re-laid weights; NULL = the fp32 stem kernels */

@@ -487,6 +487,7 @@ Train_ResNet *init_trainer(ResNet *model, Batch *cur_batch, int batch_size, floa
     c->input_reset = 1;   /* resnet.cu:2981-2982 */
     c->world = 1; c->bucket_bytes = (size_t)32 << 20;
     c->dtype = MID_F32; c->policy = MI_STORE_FAST;
+    c->fz_enable = !(getenv("RESNET_MI_BF16_BNFUSE_BWD") && atoi(getenv("RESNET_MI_BF16_BNFUSE_BWD")) == 0);
     c->overlap_wgrad = getenv("RESNET_MI_OVERLAP") ? atoi(getenv("RESNET_MI_OVERLAP")) : 1;
     c->ev_bn_done = mid_event_create(); c->ev_wgrad_done = mid_event_create();
 
@@ -794,8 +795,12 @@ static void conv_dgrad_t(Train_ResNet *t, const float *w, const float *dy, float
     MiCtx *c = ctx_of(t);
     const mid_wt_entry *we = wt_lookup(c, w);
     c->ws.pre_dgrad = we ? we->dgrad : NULL;
-    if (c->dtype == MID_BF16) ck(mid_conv_dgrad_bf16(G.compute, &c->ws, w, dy, dx, addend, t->batch_size, C, H, K, k, stride), "convolution dgrad (bf16)");
+    if (c->dtype == MID_BF16 && c->fz_req_valid) { /* ... and the reduction pass of the BN' its output feeds */
+        ck(mid_conv_dgrad_bn_bf16(G.compute, &c->ws, w, dy, dx, addend, t->batch_size, C, H, K, k, stride, &c->fz_req), "convolution dgrad + BN' reduction (bf16)");
+        if (c->fz_req.nparts > 0) { c->fz_done = c->fz_req; c->fz_ready = 1; }
+    } else if (c->dtype == MID_BF16) ck(mid_conv_dgrad_bf16(G.compute, &c->ws, w, dy, dx, addend, t->batch_size, C, H, K, k, stride), "convolution dgrad (bf16)");
     else ck(mid_conv_dgrad(G.compute, &c->ws, w, dy, dx, addend, t->batch_size, C, H, K, k, stride), "convolution dgrad");
+    c->fz_req_valid = 0;
     c->ws.pre_dgrad = NULL;
 }
 static void conv_wgrad_t(Train_ResNet *t, mid_stream st, const float *x, const float *dy, float *dw, int C, int H, int K, int k, int stride,
@@ -818,6 +823,11 @@ static void unit_bwd(Train_ResNet *t, const float *in, const float *w, const Bat
     const int x_dt = (c->dtype == MID_BF16 && !stem) ? MID_BF16 : MID_F32;
     /* BN' of this unit (HBM-bound) runs next to earlier units' weight gradients (FMA-bound, low-priority aux stream);
      * mask_mode 3: ReLU' of the block output fused in, and its product with the upstream gradient kept (gated_out) */
+    if (c->fz_ready) { /* the dgrad that produced dy gated it and left the sums: merge, finalize, apply */
+        c->fz_ready = 0;
+        ck(mid_bn_bwd_parts_t(G.compute, c->bn_ws, &c->fz_done, conv_out, x_dt, bn->gamma, bn->beta, cache->means, cache->vars, dy, c->dtype,
+                              d_conv_out, dbn->gamma, dbn->beta, N, K, Ho * Ho, t->eps), "batch norm backward (reduction done by the dgrad)");
+    } else
     ck(mid_bn_bwd_t(G.compute, c->bn_ws, conv_out, x_dt, bn->gamma, bn->beta, cache->means, cache->vars, dy, mask_src, gated_out, c->dtype,
                     d_conv_out, dbn->gamma, dbn->beta, N, K, Ho * Ho, t->eps, mask_mode), "batch norm backward");
     if (c->overlap_wgrad == 2 && d_slot >= 0) {
@@ -884,6 +894,11 @@ void backwards_pass(Train_ResNet *t) {
             dk->output = ring_take(c, NULL);
             if (b->projection) dk->transformed_residual = ring_take(c, &s_proj);
         }
+        /* bf16 + FAST: a dgrad may do the reduction pass of the BN' its output feeds (and gate that output) */
+        const int fz = c->fz_enable && c->dtype == MID_BF16; /* (RECOMPUTE_BN: the gating tensors have just been re-derived when the dgrad runs) */
+#define FZ_REQ(x_, mask_, means_) do { if (fz) { c->fz_req.x = (x_); c->fz_req.mask = (mask_); c->fz_req.means = (means_); \
+        c->fz_req.buf = c->bn_parts.buf; c->fz_req.floats = c->bn_parts.floats; c->fz_req.nparts = 0; c->fz_req_valid = 1; } } while (0)
+        const int up_gated = c->fz_ready; /* the block above's reduction dgrad already gated `up` by this block's output and summed for the expansion BN' */
         if (b->projection) {
             /* ReLU' of the block output (doActivationDeriv, :1934) is fused into the projection BN' as an external mask; that
              * pass also leaves relu'(out) * up in dk->output, which the expansion BN' then reads instead of up + mask */
@@ -897,12 +912,13 @@ void backwards_pass(Train_ResNet *t) {
             /* doActivationDeriv (:1934) rides in the expansion BN' reduce pass, which also leaves relu'(out) * up in dk->output
              * (one pass over the block output less than a separate ReLU' kernel) */
             exp_dy = up; exp_mask = k->output_activated; exp_mode = 3;
-            red_addend = dk->output; /* identity shortcut: setVal 0 + addVec (:2003-2004) folded into the dgrad epilogue */
+            red_addend = up_gated ? up : dk->output; /* identity shortcut: setVal 0 + addVec (:2003-2004) folded into the dgrad epilogue */
         }
         if (ring) { dk->post_expanded = ring_take(c, &s_exp); dk->post_spatial_activated = ring_take(c, NULL); }
         if (recompute) /* the expansion's input, re-derived: relu(BN(post_spatial)) (resnet_clean.cu:2753) */
             ck(mid_bn_apply_t(G.compute, k->post_spatial, c->dtype, b->norm_spatial->gamma, b->norm_spatial->beta, NULL, k->norm_post_spatial->means,
                               k->norm_post_spatial->vars, k->post_spatial_activated, c->dtype, N, b->reduced_depth, Ho * Ho, t->eps, 1), "BN recompute");
+        FZ_REQ(k->post_spatial, k->post_spatial_activated, k->norm_post_spatial->means); /* expansion dgrad -> spatial BN' */
         unit_bwd(t, k->post_spatial_activated, b->depth_expansion, b->norm_expansion, k->norm_post_expanded,
                  db->norm_expansion, k->post_expanded, exp_dy, exp_mask, exp_mode, dk->output, dk->post_expanded, s_exp,
                  dk->post_spatial_activated, NULL, db->depth_expansion, b->reduced_depth, Ho, b->expanded_depth, 1, 1, 0);
@@ -913,15 +929,22 @@ void backwards_pass(Train_ResNet *t) {
                               k->norm_post_reduced->means, k->norm_post_reduced->vars, k->post_reduced_activated, c->dtype, N, b->reduced_depth,
                               H * H, t->eps, 1), "BN recompute");
         g_par = c->par ? c->par[i].spatial : NULL; g_par_bytes = c->par ? c->par[i].spatial_bytes : 0;
+        FZ_REQ(k->post_reduced, k->post_reduced_activated, k->norm_post_reduced->means); /* spatial dgrad -> reduction BN' */
         unit_bwd(t, k->post_reduced_activated, b->spatial, b->norm_spatial, k->norm_post_spatial, db->norm_spatial,
                  k->post_spatial, dk->post_spatial_activated, NULL, 1, NULL, dk->post_spatial, s_spa, dk->post_reduced_activated, NULL,
                  db->spatial, b->reduced_depth, H, b->reduced_depth, 3, b->stride, 0);
         if (ring) dk->post_reduced = ring_take(c, &s_red);
+        if (i > 0 && !p->conv_blocks[i - 1]->projection) { /* reduction dgrad -> the expansion BN' of the identity block below */
+            const Activation_ConvBlock *kb = a->activation_conv_blocks[i - 1];
+            FZ_REQ(kb->post_expanded, kb->output_activated, kb->norm_post_expanded->means);
+        }
         unit_bwd(t, bin, b->depth_reduction, b->norm_depth_reduction, k->norm_post_reduced, db->norm_depth_reduction,
                  k->post_reduced, dk->post_reduced_activated, NULL, 1, NULL, dk->post_reduced, s_red, dbin, red_addend,
                  db->depth_reduction, b->incoming_filters, H, b->reduced_depth, 1, 1, 0);
         mi_dp_reduce_ready(t, (size_t)(db->depth_reduction - c->g_arena), 0);
+#undef FZ_REQ
     }
+    c->fz_ready = 0; c->fz_req_valid = 0;
     const int Hs = d->input / d->init_conv_stride;
     int s_stem = -1;
     if (ring) { da->init_conv_activated = ring_take(c, NULL); da->init_conv_applied = ring_take(c, &s_stem); }
