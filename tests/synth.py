@@ -54,6 +54,9 @@ C1_DIMS = resnet_dims(input=32, n_conv_blocks=1, reductions=(), final_depth=256)
 C1_BATCH = 4
 # a 3-block net with one striding block: exercises the 3x3-s2 projection, identity residual, toAdd
 C1S_DIMS = resnet_dims(input=32, n_conv_blocks=3, reductions=(1,), final_depth=512)
+# 4 blocks, the third one striding: an identity block FOLLOWED by another block (the upper block's reduction dgrad feeds the lower one's
+# expansion BN': the fused-reduction route of the bf16 trainer), at 8x8 and 4x4 planes
+C4I_DIMS = resnet_dims(input=32, n_conv_blocks=4, reductions=(2,), final_depth=512)
 R50_DIMS = resnet_dims()
 
 

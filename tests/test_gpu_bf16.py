@@ -8,6 +8,8 @@ round to nearest even) so the only differences left are the fp32 summation order
   fp32 outputs   (weight gradients, statistics, dgamma / dbeta)  rel-L2 <= 1e-4, the fp32 tolerance of util.py
 Whole steps (weights fp32 in the oracle, rounded to bf16 inside the product): activations rel-L2 <= 2e-2, loss |d| <= 5e-2
 (SURVEY §8c); what is measured on MI355X is recorded in DESIGN.md §2."""
+import os
+
 import numpy as np
 import pytest
 
@@ -342,10 +344,10 @@ def _make(dims, batch, oracle, dtype, policy=None):
 BLOCK_FWD = ["reduction_applied", "reduction_activated", "spatial_applied", "spatial_activated", "expanded_applied", "output_activated"]
 
 
-@pytest.mark.parametrize("cfg", ["C1", "C1S", "C1S_batch5"])
+@pytest.mark.parametrize("cfg", ["C1", "C1S", "C1S_batch5", "C4I"])
 def test_training_step_bf16_vs_fp32_oracle(oracle, cfg):
     import torch_ref
-    dims, batch = (synth.C1_DIMS, synth.C1_BATCH) if cfg == "C1" else (synth.C1S_DIMS, 5 if cfg.endswith("5") else 4)
+    dims, batch = (synth.C1_DIMS, synth.C1_BATCH) if cfg == "C1" else (synth.C4I_DIMS, 4) if cfg == "C4I" else (synth.C1S_DIMS, 5 if cfg.endswith("5") else 4)
     net, tr = _make(dims, batch, oracle, BF16)
     worst = {"act": 0.0, "grad": 0.0, "loss": 0.0, "ratio": 0.0}
     try:
@@ -383,8 +385,9 @@ def test_training_step_bf16_vs_fp32_oracle(oracle, cfg):
                 e = rel_l2(emu_grads[i].reshape(-1), ref)
                 worst["grad"] = max(worst["grad"], r)
                 worst["ratio"] = max(worst["ratio"], r / (e + 1e-2))
-                assert r <= GRAD_REL_CAP and r <= 1.5 * e + 1e-2, "gradient %d step %d: rel-L2 %.3e (bf16-rounded float64 model: %.3e)" % (i, step, r, e)
-            assert rel_l2(tr.get("grads", net.n_locations - 1), net.grad(net.n_locations - 1)) <= GRAD_FC_REL
+                cap = GRAD_REL_CAP + (0.1 if dims["n_conv_blocks"] > 3 else 0.0)  # (the inherent level grows with depth: 0.32 for the 4-block net)
+                assert r <= cap and r <= 1.5 * e + 1e-2, "gradient %d step %d: rel-L2 %.3e (bf16-rounded float64 model: %.3e)" % (i, step, r, e)
+            assert rel_l2(tr.get("grads", net.n_locations - 1), net.grad(net.n_locations - 1)) <= GRAD_FC_REL * (1.5 if dims["n_conv_blocks"] > 3 else 1.0)
             net.update()
             tr.update()
             assert tr.check_errors() == 0
@@ -467,3 +470,70 @@ def test_overlap_modes_in_bf16_are_bit_identical_and_ring_mode_is_refused():
     for g in out[1:]:
         for a, b in zip(out[0], g):
             assert np.array_equal(a, b)
+
+
+# ---- the 16-block reference-defined ResNet-50 in bf16 storage: every plane size and every kernel route of the benchmark in one net ----
+R50_BF16_FUSED_VS_NOT = 5e-2  # gradients, reductions done by the dgrads vs as passes of their own: same gates, fp32 sums in another order; a bf16
+#                               tensor downstream of a sum may flip a last bit and 48 BN backward layers amplify it (measured: worst 1.8e-2,
+#                               median 8e-3 at batch 8).  The sharp checks of that route are the operator test against the oracle at every
+#                               plane size and the whole-step configs (C4I has an identity block fed by the block above)
+
+
+@pytest.mark.gpu
+def test_resnet50_bf16_every_block_and_both_bn_backward_routes(oracle):
+    import torch_ref
+    from oracle.oracle_py import OracleNet
+    from resnet_amd import Trainer
+    from resnet_amd import binding as B
+    dims = synth.R50_DIMS
+    params = synth.make_params(dims, perturb_bn=True)
+
+    def run(batch, fused, check_forward):
+        im, lab = synth.make_batch(dims, batch, step=0)
+        os.environ["RESNET_MI_BF16_BNFUSE_BWD"] = str(fused)
+        tr = Trainer(dims, batch, **HYPER)
+        try:
+            tr.set_dtype(B.MI_DTYPE_BF16)
+            tr.set_params(params)
+            tr.source_host(B.MI_LAYOUT_NHWC)
+            tr.fill_host_batch(im, lab); tr.load_new_batch(); tr.forward(); tr.check()
+            if check_forward:
+                check_forward(tr, im, lab)
+            tr.backward(); tr.check()
+            return [tr.get("grads", i).copy() for i in range(tr.n_locations)]
+        finally:
+            tr.close()
+            os.environ.pop("RESNET_MI_BF16_BNFUSE_BWD", None)
+
+    def forward_checks(tr, im, lab):
+        # Batch 2 through 16 blocks (BN over 98-6272 samples amplifies every rounding).  The yardstick: float64 arithmetic with bf16
+        # rounding at exactly the product's storage points.  Against the fp32 oracle both sit at the same, inherent, distance
+        # (1e-2 after block 0 ... 0.48 after block 15 on this net); two executions of the rounding rule differ from each other by
+        # about half of it (values on a rounding boundary).
+        batch = len(lab)
+        net = OracleNet(oracle, dims, batch)
+        try:
+            for i, p in enumerate(params):
+                net.param(i)[:] = p
+            net.set_batch(im, lab)
+            net.forward()
+            emu = torch_ref.TorchNetBF16(dims, params, eps=HYPER["eps"])
+            emu.forward(torch_ref.nhwc_to_nchw(im), lab)
+            for b in range(dims["n_conv_blocks"]):
+                nm = "conv_blocks/%02d/output_activated" % b
+                g, m = tr.activation(nm), emu.acts["b%d_out" % b].detach().numpy()
+                r_or, r_em, e_or = rel_l2(nhwc(g), net.tensor(nm)), rel_l2(g, m), rel_l2(nhwc(m.astype(np.float32)), net.tensor(nm))
+                print("  block %2d output: HIP vs rounding model %.2e; vs the fp32 oracle: HIP %.2e, rounding model %.2e" % (b, r_em, r_or, e_or))
+                assert r_em <= e_or + 2e-3, "block %d output: rel-L2 %.3e against the bf16-rounding model (its own deviation %.3e)" % (b, r_em, e_or)
+                assert r_or <= 1.5 * e_or + 5e-3, "block %d output: %.3e from the fp32 oracle, the rounding model is %.3e" % (b, r_or, e_or)
+        finally:
+            net.close()
+
+    run(2, 1, forward_checks)
+    # the two BN-backward routes (reductions in the dgrad epilogues / as passes of their own) at batch 8: same gates, fp32 sums in
+    # another order -- a bf16 tensor downstream of a sum may flip a last bit, and 16 blocks of batch norm amplify that
+    g1, g0 = run(8, 1, None), run(8, 0, None)
+    errs = [rel_l2(a, b) for a, b in zip(g1, g0)]
+    print("  gradients, BN' reductions in the dgrad epilogues vs as passes of their own (batch 8): worst rel-L2 %.2e (location %d), median %.2e"
+          % (max(errs), int(np.argmax(errs)), float(np.median(errs))))
+    assert max(errs) <= R50_BF16_FUSED_VS_NOT, max(errs)

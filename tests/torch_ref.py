@@ -160,6 +160,7 @@ class TorchNetBF16(TorchNet):
             if inc != ex:
                 res = self._unit(x, li, ex, inc, 3 if stride == 2 else 1, stride, False, "proj"); li += 3
             x = self._unit(s, le, ex, red, 1, 1, False, "exp", residual=res)
+            self.acts["b%d_out" % b] = x
             inc = ex
         pooled = x.mean(dim=(2, 3))
         logits = pooled @ self.p[li].view(inc, d["output"])
