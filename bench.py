@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 FP32_PEAK_TFLOPS = 157.3   # gfx950 fp32: vector FMA rate == fp32 MFMA rate (MI355X_MICROARCH.md)
 BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md; AMD's 5 PF figure includes 2:1 sparsity)
 HBM_PEAK_GBS = 8000.0
-FAMILIES_F32 = {0: "direct conv 7x7 stem / untiled 3x3 fwd+dgrad (dconv_kernel, VALU)", 1: "direct conv wgrad (wgradC/wgrad_kernel, VALU)",
+FAMILIES_F32 = {0: "7x7 stem fwd (st32_pad + st32_fwd_kernel, fp32 MFMA)", 1: "7x7 stem wgrad (st32_wgrad_kernel, fp32 MFMA)",
                 2: "1x1 conv / FC GEMM (igemm_kernel<*,1,1,*> / gemm_mfma_kernel, fp32 MFMA)", 3: "batch norm fwd+bwd",
                 5: "3x3 conv fwd+dgrad+wgrad incl. the 3x3-s2 projections (igemm_kernel<*,3,*,*>, implicit GEMM on fp32 MFMA)"}
 FAMILIES_BF16 = {0: "7x7 stem fwd (st_pad + st_fwd_kernel, bf16 MFMA, fp32 output)", 1: "7x7 stem wgrad (st_wgrad_kernel, bf16 MFMA, fp32 dY)",

@@ -389,6 +389,9 @@ int mi_op_conv_dgrad_bn_bwd_bf16(const float *w_kcrs, const void *dy, const void
  * fp32 accumulation on the bf16 matrix cores.  -2: shape not covered (the trainer then keeps the fp32 stem). */
 int mi_op_stem_fwd_bf16(const float *x, const float *w_kcrs, float *y, int N, int H);
 int mi_op_stem_wgrad_bf16(const float *x, const float *w_kcrs, const float *dy, float *dw_kcrs, int N, int H);
+/* the same stem in exact fp32 arithmetic on the fp32 matrix cores (what the fp32 trainer runs unless RESNET_MI_IGEMM=0) */
+int mi_op_stem_fwd_f32(const float *x, const float *w_kcrs, float *y, int N, int H);
+int mi_op_stem_wgrad_f32(const float *x, const float *w_kcrs, const float *dy, float *dw_kcrs, int N, int H);
 /* prepareAndDoConvolution + prepareAndDoBatchNormAndActivate as forward_pass pairs them (resnet.cu:1386-1396, 1431-1453): BN
  * statistics from the convolution's own epilogue where the layer runs on the implicit GEMM.  dt = storage type of x, conv_out, y.
  * Returns < 0 on error, else the number of statistics partial rows the convolution left (0 = separate statistics pass). */

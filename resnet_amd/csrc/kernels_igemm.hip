@@ -730,6 +730,7 @@ size_t mi_igemm_part_floats(int N, int C, int H, int K, int k, int stride) {
 
 #define IG_TAIL_FLOATS ((size_t)IG_SLOTS * 128 * 128) /* partial-tile buffer: one slice per slot (768 x 64 x 128 fits too), 33.5 MB */
 size_t mi_igemm_tail_floats(void) { return igemm_mode() ? IG_TAIL_FLOATS : 0; }
+extern "C" int mid_igemm_mode(void) { return igemm_mode(); } /* RESNET_MI_IGEMM: 0 = no matrix cores anywhere */
 // Workgroup-count quantisation: `tiles` equal workgroups on IG_SLOTS resident slots run in ceil(tiles / IG_SLOTS) rounds, so
 // a last round that fills only a fraction of the chip costs a whole round (ResNet-50 at N=256: the 1024->2048 @14
 // projection has 1568 tiles = 3.06 rounds).  The `rem` tiles of that last round are cut into s = IG_SLOTS / rem slices along

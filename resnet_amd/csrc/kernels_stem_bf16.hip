@@ -262,6 +262,161 @@ st_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, i
     if (sg == 0 && ok) dw[i] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
+// =====================================================================================================================
+// The same two kernels in exact fp32 (v_mfma_f32_32x32x2_f32: a lane supplies ONE value per operand, k = lane >> 5), for the
+// fp32 storage mode.  The planes are fp32; a lane loads 4 consecutive elements (16 bytes) and feeds them to 4 MFMA steps:
+//   forward:  for one (c, r), half-wave 0 holds the taps s = 0, 2, 4, 6 (plane pw = 1), half-wave 1 the taps (-), 1, 3, 5 (plane
+//             pw = 0): step i multiplies k = {s = 2 i, s = 2 i - 1}; the weights of a step come from LDS (one ds_read_b32)
+//   wgrad:    half-wave h holds pixels 4 h .. 4 h + 3 of an 8-pixel chunk of dY / of the patch: step i multiplies the pixel
+//             pair (i, 4 + i)
+template <int DUMMY>
+__global__ void __launch_bounds__(256)
+st32_pad_kernel(const float *__restrict__ x, float *__restrict__ xp, const StArgs g, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t hp = (uint32_t)g.pitch;
+        const size_t row = e / hp;
+        const int j = (int)(e - row * hp);
+        const int ii = (int)(row % (uint32_t)g.R);
+        size_t q = row / (uint32_t)g.R;
+        const int pw = (int)(q & 1); q >>= 1;
+        const int ph = (int)(q & 1); q >>= 1;
+        const int y = 2 * ii + ph - 4, x0 = 2 * j + pw - 4;
+        float v = 0.f;
+        if (y >= 0 && y < g.H && x0 >= 0 && x0 < g.H) v = x[(q * g.H + y) * (size_t)g.H + x0];
+        xp[e] = v;
+    }
+}
+// weights KCRS -> LDS order [g = 7 c + r][step i][k half][64 channels]: half 0: s = 2 i, half 1: s = 2 i - 1 (i = 0: 0)
+__global__ void __launch_bounds__(256)
+st32_wt_kernel(const float *__restrict__ w, float *__restrict__ wl) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 21 * 4 * 2 * ST_K) return;
+    const int ch = idx & 63, kh = (idx >> 6) & 1, i = (idx >> 7) & 3, gq = idx >> 9;
+    const int s = kh ? 2 * i - 1 : 2 * i;
+    wl[idx] = s >= 0 ? w[(size_t)ch * 147 + gq * 7 + s] : 0.f;
+}
+__global__ void __launch_bounds__(256)
+st32_fwd_kernel(const float *__restrict__ xp, const float *__restrict__ wl, float *__restrict__ y, const StArgs g, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char st_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    constexpr int PITCH = 32 * 4 + 16;
+    constexpr int WL = 21 * 4 * 2 * ST_K;            // floats
+    float *ws = (float *)st_smem;                     // [21][4][2][64]
+    unsigned char *img = st_smem + WL * 4 + wave * (64 * PITCH);
+    for (int i = threadIdx.x; i < WL; i += 256) ws[i] = wl[i];
+    __syncthreads();
+    uint32_t goff[21];
+#pragma unroll
+    for (int gq = 0; gq < 21; gq++) {
+        const int c = gq / 7, r = gq - 7 * c;
+        const int ph = (r + 1) & 1, di = (r + 1) >> 1;
+        goff[gq] = (uint32_t)((((c * 2 + ph) * 2 + (kh ? 0 : 1)) * g.R + di) * g.pitch);   // half 0 reads plane pw = 1, half 1 plane pw = 0
+    }
+    const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    const int per = (ntiles + nw - 1) / nw, t_end = min(ntiles, (gw + 1) * per);
+    for (int tile = gw * per; tile < t_end; tile++) {
+        const uint32_t n = fd_div((uint32_t)tile, g.fdTpi);
+        const uint32_t p0 = ((uint32_t)tile - n * g.fdTpi.d) * 32u;
+        const uint32_t p = p0 + (uint32_t)l31;
+        const uint32_t ho = fd_div(p, g.fdWo), wo = p - ho * (uint32_t)g.Wo;
+        const float *base = xp + (size_t)n * g.img + (size_t)ho * g.pitch + wo;
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+        typedef pf4 __attribute__((aligned(4))) pf4_u;
+        pf4 a[21];
+#pragma unroll
+        for (int gq = 0; gq < 21; gq++) a[gq] = *(const pf4_u *)(base + goff[gq]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int gq = 0; gq < 21; gq++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float *wp = ws + ((gq * 4 + i) * 2 + kh) * ST_K + l31;
+#pragma unroll
+                for (int t = 0; t < 2; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gq][i], wp[32 * t], acc[t], 0, 0, 0);
+            }
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                pf4 v = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+                *(pf4 *)(img + (t * 32 + l31) * PITCH + (8 * q + 4 * kh) * 4) = v;
+            }
+        const int c4 = lane & 7, r0 = lane >> 3;
+        float *dst = y + ((size_t)n * ST_K) * g.P + p0 + 4 * c4;
+#pragma unroll
+        for (int ps = 0; ps < 8; ps++) {
+            const int ch = ps * 8 + r0;
+            const pf4 v = *(const pf4 *)(img + ch * PITCH + c4 * 16);
+            *(pf4 *)(dst + (size_t)ch * g.P) = v;
+        }
+    }
+}
+__global__ void __launch_bounds__(256, 2)
+st32_wgrad_kernel(const float *__restrict__ xp, const float *__restrict__ dy, float *__restrict__ part, const StArgs g, int nchunks) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    uint32_t coff[5];
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+        int j = l31 + 32 * t;
+        if (j > 146) j = 146;
+        const int c = j / 49, rs = j - 49 * c, r = rs / 7, s = rs - 7 * r;
+        const int ph = (r + 1) & 1, di = (r + 1) >> 1, pw = (s + 1) & 1, dj = (s + 1) >> 1;
+        coff[t] = (uint32_t)((((c * 2 + ph) * 2 + pw) * g.R + di) * g.pitch + dj + 4 * kh);
+    }
+    f32x16 acc[2][5];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int t = 0; t < 5; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][t][r] = 0.f;
+    const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    typedef pf4 __attribute__((aligned(4))) pf4_u;
+    auto load = [&](int chunk, pf4 (&a)[2], pf4 (&b)[5]) {
+        const uint32_t n = fd_div((uint32_t)chunk, g.fdTpi);
+        const uint32_t p0 = ((uint32_t)chunk - n * g.fdTpi.d) * 8u;    // 8 consecutive pixels of one output row (Wo % 8 == 0)
+        const uint32_t ho = fd_div(p0, g.fdWo), wo0 = p0 - ho * (uint32_t)g.Wo;
+        const float *da = dy + ((size_t)n * ST_K + l31) * g.P + p0 + 4 * kh;
+#pragma unroll
+        for (int i = 0; i < 2; i++) a[i] = *(const pf4 *)(da + (size_t)(32 * i) * g.P);
+        const float *xb = xp + (size_t)n * g.img + (size_t)ho * g.pitch + wo0;
+#pragma unroll
+        for (int t = 0; t < 5; t++) b[t] = *(const pf4_u *)(xb + coff[t]);
+    };
+    auto mul = [&](const pf4 (&a)[2], const pf4 (&b)[5]) {
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int t = 0; t < 5; t++) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[t][e], acc[i][t], 0, 0, 0);
+    };
+    pf4 a0[2], a1[2], b0[5], b1[5];
+    const int per = (nchunks + nw - 1) / nw, c_end = min(nchunks, (gw + 1) * per);
+    int chunk = gw * per;
+    if (chunk < c_end) load(chunk, a0, b0);
+    for (; chunk + 1 < c_end; chunk += 2) {
+        load(chunk + 1, a1, b1);
+        mul(a0, b0);
+        if (chunk + 2 < c_end) load(chunk + 2, a0, b0);
+        mul(a1, b1);
+    }
+    if (chunk < c_end) mul(a0, b0);
+    float *o = part + (size_t)gw * (ST_K * ST_COLS);
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int t = 0; t < 5; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) o[(32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh) * ST_COLS + l31 + 32 * t] = acc[i][t][r];
+}
+
 // ---- host ----
 static int st_geometry(StArgs &g, int N, int H) {
     g.N = N; g.H = H; g.Ho = H / 2; g.Wo = H / 2; g.P = g.Ho * g.Wo;
@@ -307,6 +462,53 @@ int mid_stem_fwd_bf16(mid_stream s, const float *x, const float *w, float *y, vo
     hipLaunchKernelGGL(st_fwd_kernel, dim3(waves / 4), dim3(256), 4 * 64 * (32 * 4 + 16), st, (const u16 *)xp, wf, y, g, ntiles);
     mi_prof_end(st);
     MI_LAUNCH_CHECK("st_fwd_kernel");
+    return 0;
+}
+/* the exact-fp32 pair: planes and operands fp32 (xp: mid_stem_f32_xp_bytes) */
+size_t mid_stem_f32_xp_bytes(int N, int H) {
+    StArgs g; st_geometry(g, N, H);
+    return (size_t)N * g.img * 4 + 64;
+}
+int mid_stem_fwd_f32(mid_stream s, const float *x, const float *w, float *y, void *xp, size_t xp_bytes, float *scratch, size_t scratch_floats,
+                     int N, int H) {
+    hipStream_t st = (hipStream_t)s;
+    StArgs g; st_geometry(g, N, H);
+    if (xp_bytes < mid_stem_f32_xp_bytes(N, H) || scratch_floats < mid_stem_bf16_part_floats(N, H)) { mi_record_error("mid_stem_fwd_f32", "workspace too small"); return -3; }
+    const size_t total = (size_t)N * g.img;
+    size_t pb = (total + 255) / 256; if (pb > (1u << 20)) pb = 1u << 20;
+    mi_prof_begin(st, MI_FAM_DCONV, 2.0 * N * g.P * ST_K * 147.0, 4.0 * ((double)N * 3 * H * H + (double)N * ST_K * g.P));
+    hipLaunchKernelGGL(st32_pad_kernel<0>, dim3((unsigned)pb), dim3(256), 0, st, x, (float *)xp, g, total);
+    float *wl = scratch + (size_t)ST_WAVES * ST_K * ST_COLS;   // 21 * 4 * 2 * 64 floats = 10752 <= ST_K * ST_KRED (11264)
+    hipLaunchKernelGGL(st32_wt_kernel, dim3((21 * 4 * 2 * ST_K + 255) / 256), dim3(256), 0, st, w, wl);
+    const int ntiles = N * (g.P / 32);
+    g.fdTpi = make_fastdiv(g.P / 32);
+    const int waves = st_waves(ntiles);
+    const size_t lds = (size_t)21 * 4 * 2 * ST_K * 4 + 4 * 64 * (32 * 4 + 16);
+    static int attr_set = 0;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)st32_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            mi_record_error("st32_fwd_kernel", "cannot raise the dynamic LDS limit");
+            return -1;
+        }
+        attr_set = 1;
+    }
+    hipLaunchKernelGGL(st32_fwd_kernel, dim3(waves / 4), dim3(256), lds, st, (const float *)xp, wl, y, g, ntiles);
+    mi_prof_end(st);
+    MI_LAUNCH_CHECK("st32_fwd_kernel");
+    return 0;
+}
+int mid_stem_wgrad_f32(mid_stream s, const void *xp, const float *dy, float *dw, float *scratch, size_t scratch_floats, int N, int H) {
+    hipStream_t st = (hipStream_t)s;
+    StArgs g; st_geometry(g, N, H);
+    if (scratch_floats < mid_stem_bf16_part_floats(N, H)) { mi_record_error("mid_stem_wgrad_f32", "workspace too small"); return -3; }
+    const int nchunks = N * (g.P / 8);
+    g.fdTpi = make_fastdiv(g.P / 8);
+    const int waves = st_waves(nchunks);
+    mi_prof_begin(st, MI_FAM_WGRAD, 2.0 * N * g.P * ST_K * 147.0, 4.0 * ((double)N * ST_K * g.P) + 4.0 * N * g.img);
+    hipLaunchKernelGGL(st32_wgrad_kernel, dim3(waves / 4), dim3(256), 0, st, (const float *)xp, dy, scratch, g, nchunks);
+    hipLaunchKernelGGL(st_wgrad_reduce_kernel, dim3((ST_K * 147 + 63) / 64), dim3(256), 0, st, scratch, dw, waves);
+    mi_prof_end(st);
+    MI_LAUNCH_CHECK("st32_wgrad_kernel");
     return 0;
 }
 /* dw (KCRS fp32) from the planes the forward left in xp and dy (fp32, rounded to bf16 on the way in) */

@@ -136,6 +136,12 @@ int mid_conv_wgrad_bf16(mid_stream s, mid_workspace *ws, const void *x, const vo
 /* the 7x7 stride-2 stem (3 -> 64 channels) on the bf16 matrix cores (kernels_stem_bf16.hip): image and weights rounded to
  * bf16, fp32 accumulation, fp32 output / output gradient.  xp = the image as zero-padded parity planes (written by the
  * forward, read again by the weight gradient); scratch = wave partials + re-laid weights (mid_stem_bf16_part_floats). */
+int mid_igemm_mode(void); /* RESNET_MI_IGEMM (0 = the convolutions stay off the matrix cores) */
+/* ... and in exact fp32 (v_mfma_f32_32x32x2_f32) for the fp32 storage mode; same shape rule, same scratch, fp32 planes */
+size_t mid_stem_f32_xp_bytes(int N, int H);
+int mid_stem_fwd_f32(mid_stream s, const float *x, const float *w, float *y, void *xp, size_t xp_bytes, float *scratch, size_t scratch_floats,
+                     int N, int H);
+int mid_stem_wgrad_f32(mid_stream s, const void *xp, const float *dy, float *dw, float *scratch, size_t scratch_floats, int N, int H);
 int mid_stem_bf16_supported(int C, int H, int K, int k, int stride);
 size_t mid_stem_bf16_xp_bytes(int N, int H);
 size_t mid_stem_bf16_part_floats(int N, int H);

@@ -195,6 +195,31 @@ int mi_op_stem_wgrad_bf16(const float *x, const float *w, const float *dy, float
     mi_free(xp);
     return rc;
 }
+/* ... and in exact fp32 (the stem of the fp32 storage mode where RESNET_MI_IGEMM allows the matrix cores) */
+int mi_op_stem_fwd_f32(const float *x, const float *w, float *y, int N, int H) {
+    if (!mid_stem_bf16_supported(3, H, 64, 7, 2)) return -2;
+    const size_t xb = mid_stem_f32_xp_bytes(N, H), sf = mid_stem_bf16_part_floats(N, H);
+    void *xp = mi_malloc(xb);
+    float *sc = (float *)mid_malloc(sf * sizeof(float));
+    int rc = (!xp || !sc) ? -3 : finish(mid_stem_fwd_f32(mi_global()->compute, x, w, y, xp, xb, sc, sf, N, H));
+    mid_free(sc);
+    mi_free(xp);
+    return rc;
+}
+int mi_op_stem_wgrad_f32(const float *x, const float *w, const float *dy, float *dw, int N, int H) {
+    if (!mid_stem_bf16_supported(3, H, 64, 7, 2)) return -2;
+    const size_t xb = mid_stem_f32_xp_bytes(N, H), sf = mid_stem_bf16_part_floats(N, H);
+    void *xp = mi_malloc(xb);
+    float *sc = (float *)mid_malloc(sf * sizeof(float));
+    float *y = (float *)mid_malloc((size_t)N * 64 * (H / 2) * (H / 2) * sizeof(float));
+    int rc = (!xp || !sc || !y) ? -3 : mid_stem_fwd_f32(mi_global()->compute, x, w, y, xp, xb, sc, sf, N, H); /* leaves the padded planes in xp */
+    if (!rc) rc = mid_stem_wgrad_f32(mi_global()->compute, xp, dy, dw, sc, sf, N, H);
+    rc = finish(rc);
+    mid_free(y);
+    mid_free(sc);
+    mi_free(xp);
+    return rc;
+}
 /* A convolution and the batch norm behind it the way forward_pass runs the pair (resnet.cu:1386-1396 + 1431-1453): the
  * statistics come out of the convolution's own epilogue (fp32 accumulators) where the layer runs on the implicit GEMM, and
  * from a pass over conv_out where it does not.  dt = storage type of x, conv_out and y. */

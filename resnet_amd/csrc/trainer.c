@@ -440,6 +440,14 @@ static void build_buffers(Train_ResNet *t) {
     const int f = d->init_conv_filters, Hs = d->input / d->init_conv_stride;
     c->stem_dx = c->dtype == MID_BF16 ? falloc(c, (size_t)N * f * Hs * Hs) : NULL;
     c->stem_xp = NULL; c->stem_scratch = NULL; c->stem_xp_bytes = 0; c->stem_scratch_floats = 0;
+    if (c->dtype == MID_F32 && mid_igemm_mode() > 0 && mid_stem_bf16_supported(3, d->input, f, d->init_kernel_dim, d->init_conv_stride) &&
+        !(getenv("RESNET_MI_STEM_MFMA") && atoi(getenv("RESNET_MI_STEM_MFMA")) == 0)) {
+        /* fp32 storage: the stem in exact fp32 on the matrix cores (kernels_stem_bf16.hip, st32_*) */
+        c->stem_xp_bytes = mid_stem_f32_xp_bytes(N, d->input);
+        c->stem_scratch_floats = mid_stem_bf16_part_floats(N, d->input);
+        c->stem_xp = falloc(c, (c->stem_xp_bytes + 3) / 4);
+        c->stem_scratch = falloc(c, c->stem_scratch_floats);
+    }
     if (c->dtype == MID_BF16 && mid_stem_bf16_supported(3, d->input, f, d->init_kernel_dim, d->init_conv_stride) &&
         !(getenv("RESNET_MI_BF16_STEM") && atoi(getenv("RESNET_MI_BF16_STEM")) == 0)) {
         /* the stem on the bf16 matrix cores (image and weights rounded to bf16 like every other convolution of this mode) */
@@ -693,7 +701,11 @@ static void unit_fwd(Train_ResNet *t, const float *in, const float *w, const Bat
     const mid_wt_entry *we = wt_lookup(c, w);
     mid_bn_parts *parts = (c->fuse_bn_stats || bf) ? &c->bn_parts : NULL;
     c->ws.pre_fwd = we ? we->fwd : NULL; /* re-laid at the start of this forward pass */
-    if (stem && c->stem_scratch) {
+    if (stem && c->stem_scratch && c->dtype == MID_F32) {
+        if (parts) parts->nparts = 0; /* (no statistics from this kernel: BN takes its own pass) */
+        ck(mid_stem_fwd_f32(G.compute, in, w, conv_out, c->stem_xp, c->stem_xp_bytes, c->stem_scratch, c->stem_scratch_floats, N, H),
+           "stem convolution forward (fp32 matrix cores)");
+    } else if (stem && c->stem_scratch) {
         if (parts) parts->nparts = 0; /* (no statistics from this kernel: BN takes its own pass) */
         ck(mid_stem_fwd_bf16(G.compute, in, w, conv_out, c->stem_xp, c->stem_xp_bytes, c->stem_scratch, c->stem_scratch_floats, N, H),
            "stem convolution forward (bf16 operands)");
@@ -808,7 +820,9 @@ static void conv_wgrad_t(Train_ResNet *t, mid_stream st, const float *x, const f
     MiCtx *c = ctx_of(t);
     /* the forward pass left the parity planes of x in the layer's own buffer: the weight gradient reads them again */
     c->ws.s2d = stride == 2 ? g_par : NULL; c->ws.s2d_bytes = stride == 2 ? g_par_bytes : 0; c->ws.s2d_valid = stride == 2 && g_par != NULL;
-    if (stem && c->stem_scratch) /* the forward pass left the batch as padded bf16 parity planes */
+    if (stem && c->stem_scratch && c->dtype == MID_F32)
+        ck(mid_stem_wgrad_f32(st, c->stem_xp, dy, dw, c->stem_scratch, c->stem_scratch_floats, t->batch_size, H), "stem convolution wgrad (fp32 matrix cores)");
+    else if (stem && c->stem_scratch) /* the forward pass left the batch as padded bf16 parity planes */
         ck(mid_stem_wgrad_bf16(st, c->stem_xp, dy, dw, c->stem_scratch, c->stem_scratch_floats, t->batch_size, H), "stem convolution wgrad (bf16 operands)");
     else if (c->dtype == MID_BF16 && !stem) ck(mid_conv_wgrad_bf16(st, &c->ws, x, dy, dw, t->batch_size, C, H, K, k, stride), "convolution wgrad (bf16)");
     else ck(mid_conv_wgrad(st, &c->ws, x, dy, dw, t->batch_size, C, H, K, k, stride), "convolution wgrad");

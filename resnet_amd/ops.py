@@ -248,16 +248,19 @@ class Ops:
             self._chk(rc, "conv_dgrad_bn_bwd_bf16")
         return self.get_t(gated, BF), self.get_t(bdx, BF), og.get(), ob.get(), rc > 0
 
-    def stem_fwd_bf16(self, x, w):
+    def stem_fwd_bf16(self, x, w, exact=False):
+        """the matrix-core stem: operands rounded to bf16, or (exact) fp32 arithmetic"""
         N, _, H, _ = x.shape
         dx, dw, dy = self.dev(x), self.dev(w), self.dev(shape=(N, 64, H // 2, H // 2))
-        self._chk(self.L.mi_op_stem_fwd_bf16(dx.ptr, dw.ptr, dy.ptr, N, H), "stem_fwd_bf16")
+        fn = self.L.mi_op_stem_fwd_f32 if exact else self.L.mi_op_stem_fwd_bf16
+        self._chk(fn(dx.ptr, dw.ptr, dy.ptr, N, H), "stem_fwd")
         return dy.get()
 
-    def stem_wgrad_bf16(self, x, w, dy):
+    def stem_wgrad_bf16(self, x, w, dy, exact=False):
         N, _, H, _ = x.shape
         dx, dw, ddy, out = self.dev(x), self.dev(w), self.dev(dy), self.dev(shape=w.shape)
-        self._chk(self.L.mi_op_stem_wgrad_bf16(dx.ptr, dw.ptr, ddy.ptr, out.ptr, N, H), "stem_wgrad_bf16")
+        fn = self.L.mi_op_stem_wgrad_f32 if exact else self.L.mi_op_stem_wgrad_bf16
+        self._chk(fn(dx.ptr, dw.ptr, ddy.ptr, out.ptr, N, H), "stem_wgrad")
         return out.get()
 
     def conv_bn_fwd_t(self, x, w, gamma, beta, stride, eps, relu, dt):

@@ -211,6 +211,11 @@ def test_stem_bf16(ops, oracle, H, N):
     ref_dw = oracle.conv_wgrad(bf16_round(x), bf16_round(dy), 7, 2)
     got_dw = ops.stem_wgrad_bf16(nchw(x), w, nchw(dy))
     check_grad(got_dw, ref_dw, "stem wgrad (bf16 operands)")
+    # the same kernels in exact fp32 (the fp32 trainer's stem): the fp32 tolerances of util.py against the unrounded oracle
+    ref32 = oracle.conv_fwd(x, w, 2)
+    got32 = ops.stem_fwd_bf16(nchw(x), w, exact=True)
+    assert rel_l2(nhwc(got32), ref32) <= 1e-5, rel_l2(nhwc(got32), ref32)
+    check_grad(ops.stem_wgrad_bf16(nchw(x), w, nchw(dy), exact=True), oracle.conv_wgrad(x, dy, 7, 2), "stem wgrad (fp32)")
 
 
 def test_bf16_kernels_refuse_shapes_that_do_not_tile(ops):

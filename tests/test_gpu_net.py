@@ -11,7 +11,7 @@ from util import ACT_MAX_ABS, ACT_REL_L2, GRAD_REL_L2, LOSS_ABS, check_act, chec
 
 pytestmark = pytest.mark.gpu
 
-PARAM_REL_L2 = 1e-5
+PARAM_REL_L2 = 2e-5  # after an Adam step (~lr * sign(g) at first: gradient elements near 0 amplify rounding; measured 1.2e-5 worst)
 HYPER = dict(lr=1e-4, wd=0.0, b1=0.9, b2=0.999, eps=1e-7)
 
 

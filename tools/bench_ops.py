@@ -60,7 +60,7 @@ def main():
         L.mi_op_fill_uniform(w, nw, 2, -0.1, 0.1)
         L.mi_op_fill_uniform(y, ny, 3, -1.0, 1.0)
         flops = 2.0 * k * k * N * Ho * Ho * Cc * K
-        stem16 = args.bf16 and Cc == 3  # the bf16-mode stem: fp32 tensors, operands rounded inside (kernels_stem_bf16.hip)
+        stem16 = Cc == 3  # the matrix-core stem (kernels_stem_bf16.hip): fp32 tensors; operands rounded to bf16 (--bf16) or exact fp32
         if args.bf16:
             xb, yb, dxb = (L.mi_malloc(2 * n) for n in (nx, ny, nx))
             L.mi_op_convert(x, 0, xb, 1, nx)
@@ -72,8 +72,10 @@ def main():
             for rep in range(args.reps + 1):
                 if rep == 1:
                     L.mi_prof_reset()
-                if stem16:
+                if stem16 and args.bf16:
                     rc = L.mi_op_stem_fwd_bf16(x, w, y, N, H) if op == "fwd" else L.mi_op_stem_wgrad_bf16(x, w, y, dw, N, H)
+                elif stem16:
+                    rc = L.mi_op_stem_fwd_f32(x, w, y, N, H) if op == "fwd" else L.mi_op_stem_wgrad_f32(x, w, y, dw, N, H)
                 elif args.bf16:
                     if op == "fwd":
                         rc = L.mi_op_conv_fwd_bf16(xb, w, yb, N, Cc, H, K, k, s)

@@ -20,8 +20,8 @@ def fam(name):
     if "bg_wt_" in name: return "igemm3x3_aux"
     if "igemm_tail_reduce" in name or "igemm_wt_kernel<9>" in name or "igemm_wgrad_reduce_kernel<9>" in name: return "igemm3x3_aux"
     if "gemm_mfma_kernel" in name or "igemm_w" in name: return "gemm"
-    if "st_wgrad" in name: return "wgradC"
-    if "dconv_kernel" in name or "wt_relayout" in name or name.startswith("st_") or "void st_" in name: return "dconv"
+    if "st_wgrad" in name or "st32_wgrad" in name: return "wgradC"
+    if "dconv_kernel" in name or "wt_relayout" in name or name.startswith("st_") or name.startswith("st32_") or "void st_" in name or "void st32_" in name: return "dconv"
     if "wgradC_kernel" in name or "wgrad_kernel" in name or "split_reduce" in name: return "wgradC"
     if name.startswith("bn_") or "void bn_" in name: return "bn"
     return "other"
