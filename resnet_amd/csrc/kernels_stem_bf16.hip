@@ -19,6 +19,8 @@
 //     the partials in wave order (deterministic) into KCRS.
 // Bounds: both kernels are bound by the fp32 tensor they stream (822 MB at N = 256: 0.16 ms at 5 TB/s); MFMA time 26 us.
 #include <stdlib.h>
+#include <type_traits>
+#include <utility>
 #include "mi_common.hpp"
 #include "mi_device.h"
 
@@ -34,6 +36,9 @@ typedef u32x2 __attribute__((aligned(2))) u32x2_u;
 #ifndef ST_ABL
 #define ST_ABL 0 /* experiments: 1 no output stores, 2 aligned patch loads (wrong results), 3 no patch loads */
 #endif
+// compile-time loop: f(integral_constant<int, 0>{}) ... f(integral_constant<int, N - 1>{})
+template <class F, int... I> __device__ __forceinline__ void st_static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void st_static_for(F &&f) { st_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 #define ST_K 64        /* output channels */
 #define ST_KRED 176    /* forward reduction: 22 groups of 8 */
 #define ST_COLS 160    /* weight-gradient columns: 147 (c, r, s) padded to 5 x 32 */
@@ -166,8 +171,11 @@ st_fwd_kernel(const u16 *__restrict__ xp, const u16 *__restrict__ wf, float *__r
 }
 
 // ---- weight gradient: per-wave partials [wave][64][160] ----
-__global__ void __launch_bounds__(256, 2)
+// NS register sets of operands in a ring (see st32_wgrad_kernel below for why the loads are unconditional): a chunk's 10 MFMAs are
+// 320 cycles, so seven chunks of loads are kept in flight; one wave per SIMD.
+__global__ void __launch_bounds__(256)
 st_wgrad_kernel(const u16 *__restrict__ xp, const float *__restrict__ dy, float *__restrict__ part, const StArgs g, int nchunks) {
+    constexpr int NS = 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
     // B operand: column j = l31 + 32 t = (c * 7 + r) * 7 + s; 8 consecutive pixels of its parity plane
@@ -188,48 +196,49 @@ st_wgrad_kernel(const u16 *__restrict__ xp, const float *__restrict__ dy, float 
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][t][r] = 0.f;
     const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
-    auto load = [&](int chunk, pf4 (&a)[2][2], u32x4 (&b)[5]) {
-        const uint32_t n = fd_div((uint32_t)chunk, g.fdTpi);
-        const uint32_t p0 = ((uint32_t)chunk - n * g.fdTpi.d) * 16u;   // 16 consecutive pixels of one output row (Wo % 16 == 0)
-        const uint32_t ho = fd_div(p0, g.fdWo), wo0 = p0 - ho * (uint32_t)g.Wo;
-        const float *da = dy + ((size_t)n * ST_K + l31) * g.P + p0 + 8 * kh;
+    // a wave owns a CONTIGUOUS range of chunks: its 64 dY rows and its plane rows are sequential streams
+    const int per = (nchunks + nw - 1) / nw, c_beg = gw * per, c_end = min(nchunks, (gw + 1) * per);
+    pf4 a[NS][2][2];
+    u32x4 b[NS][5];
+    if (c_beg < c_end) {
+        auto load = [&](int chunk, auto set_tag) {
+            constexpr int S = decltype(set_tag)::value;
+            chunk = min(chunk, c_end - 1);
+            const uint32_t n = fd_div((uint32_t)chunk, g.fdTpi);
+            const uint32_t p0 = ((uint32_t)chunk - n * g.fdTpi.d) * 16u;   // 16 consecutive pixels of one output row (Wo % 16 == 0)
+            const uint32_t ho = fd_div(p0, g.fdWo), wo0 = p0 - ho * (uint32_t)g.Wo;
+            const float *da = dy + ((size_t)n * ST_K + l31) * g.P + p0 + 8 * kh;
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            a[i][0] = *(const pf4 *)(da + (size_t)(32 * i) * g.P);
-            a[i][1] = *(const pf4 *)(da + (size_t)(32 * i) * g.P + 4);
-        }
-        const u16 *xb = xp + (size_t)n * g.img + (size_t)ho * g.pitch + wo0;
+            for (int i = 0; i < 2; i++) {
+                a[S][i][0] = *(const pf4 *)(da + (size_t)(32 * i) * g.P);
+                a[S][i][1] = *(const pf4 *)(da + (size_t)(32 * i) * g.P + 4);
+            }
+            const u16 *xb = xp + (size_t)n * g.img + (size_t)ho * g.pitch + wo0;
 #pragma unroll
-        for (int t = 0; t < 5; t++) b[t] = *(const u32x4_u *)(xb + coff[t]);
-    };
-    auto mul = [&](const pf4 (&a)[2][2], const u32x4 (&b)[5]) {
-        bf16x8 av[2];
+            for (int t = 0; t < 5; t++) b[S][t] = *(const u32x4_u *)(xb + coff[t]);
+        };
+        auto mul = [&](auto set_tag) {
+            constexpr int S = decltype(set_tag)::value;
+            bf16x8 av[2];
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const u32x4 pk = {mi_pack_bf2(a[i][0][0], a[i][0][1]), mi_pack_bf2(a[i][0][2], a[i][0][3]), mi_pack_bf2(a[i][1][0], a[i][1][1]),
-                              mi_pack_bf2(a[i][1][2], a[i][1][3])};
-            av[i] = *(const bf16x8 *)&pk;
-        }
+            for (int i = 0; i < 2; i++) {
+                const u32x4 pk = {mi_pack_bf2(a[S][i][0][0], a[S][i][0][1]), mi_pack_bf2(a[S][i][0][2], a[S][i][0][3]),
+                                  mi_pack_bf2(a[S][i][1][0], a[S][i][1][1]), mi_pack_bf2(a[S][i][1][2], a[S][i][1][3])};
+                av[i] = *(const bf16x8 *)&pk;
+            }
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+            for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int t = 0; t < 5; t++) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], *(const bf16x8 *)&b[t], acc[i][t], 0, 0, 0);
-    };
-    // a wave owns a CONTIGUOUS range of chunks (its 64 dY rows and its plane rows are sequential streams) and keeps TWO chunks of
-    // operands in registers: set 1 is loaded while set 0 is multiplied and the other way round (no copies, so the compiler's
-    // s_waitcnt before a multiply counts exactly the younger set's loads)
-    pf4 a0[2][2], a1[2][2];
-    u32x4 b0[5], b1[5];
-    const int per = (nchunks + nw - 1) / nw, c_end = min(nchunks, (gw + 1) * per);
-    int chunk = gw * per;
-    if (chunk < c_end) load(chunk, a0, b0);
-    for (; chunk + 1 < c_end; chunk += 2) {
-        load(chunk + 1, a1, b1);
-        mul(a0, b0);
-        if (chunk + 2 < c_end) load(chunk + 2, a0, b0);
-        mul(a1, b1);
+                for (int t = 0; t < 5; t++) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], *(const bf16x8 *)&b[S][t], acc[i][t], 0, 0, 0);
+        };
+        st_static_for<NS - 1>([&](auto J) { load(c_beg + decltype(J)::value, J); });
+        for (int chunk = c_beg; chunk < c_end; chunk += NS)
+            st_static_for<NS>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                load(chunk + j + NS - 1, std::integral_constant<int, (j + NS - 1) % NS>{});
+                if (chunk + j < c_end) mul(J);
+            });
     }
-    if (chunk < c_end) mul(a0, b0);
     // accumulator (i, t): rows = channels 32 i + (r & 3) + 8 (r >> 2) + 4 kh, column = l31 + 32 t
     float *o = part + (size_t)gw * (ST_K * ST_COLS);
 #pragma unroll
@@ -356,8 +365,12 @@ st32_fwd_kernel(const float *__restrict__ xp, const float *__restrict__ wl, floa
         }
     }
 }
-__global__ void __launch_bounds__(256, 2)
+// NS register sets of operands in a ring: the loads of chunks j + 1 .. j + NS - 1 are in flight while chunk j is multiplied (one
+// wave per SIMD; a chunk's 40 MFMAs are 640 cycles, HBM latency several thousand).  Every load is unconditional -- past the
+// wave's range it re-reads the last chunk -- so that the compiler's s_waitcnt before a multiply counts exactly the younger sets.
+__global__ void __launch_bounds__(256)
 st32_wgrad_kernel(const float *__restrict__ xp, const float *__restrict__ dy, float *__restrict__ part, const StArgs g, int nchunks) {
+    constexpr int NS = 6;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
     uint32_t coff[5];
@@ -377,37 +390,40 @@ st32_wgrad_kernel(const float *__restrict__ xp, const float *__restrict__ dy, fl
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][t][r] = 0.f;
     const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    const int per = (nchunks + nw - 1) / nw, c_beg = gw * per, c_end = min(nchunks, (gw + 1) * per);
     typedef pf4 __attribute__((aligned(4))) pf4_u;
-    auto load = [&](int chunk, pf4 (&a)[2], pf4 (&b)[5]) {
-        const uint32_t n = fd_div((uint32_t)chunk, g.fdTpi);
-        const uint32_t p0 = ((uint32_t)chunk - n * g.fdTpi.d) * 8u;    // 8 consecutive pixels of one output row (Wo % 8 == 0)
-        const uint32_t ho = fd_div(p0, g.fdWo), wo0 = p0 - ho * (uint32_t)g.Wo;
-        const float *da = dy + ((size_t)n * ST_K + l31) * g.P + p0 + 4 * kh;
+    pf4 a[NS][2], b[NS][5];
+    if (c_beg < c_end) {
+        auto load = [&](int chunk, auto set_tag) {
+            constexpr int S = decltype(set_tag)::value;
+            chunk = min(chunk, c_end - 1);
+            const uint32_t n = fd_div((uint32_t)chunk, g.fdTpi);
+            const uint32_t p0 = ((uint32_t)chunk - n * g.fdTpi.d) * 8u;    // 8 consecutive pixels of one output row (Wo % 8 == 0)
+            const uint32_t ho = fd_div(p0, g.fdWo), wo0 = p0 - ho * (uint32_t)g.Wo;
+            const float *da = dy + ((size_t)n * ST_K + l31) * g.P + p0 + 4 * kh;
 #pragma unroll
-        for (int i = 0; i < 2; i++) a[i] = *(const pf4 *)(da + (size_t)(32 * i) * g.P);
-        const float *xb = xp + (size_t)n * g.img + (size_t)ho * g.pitch + wo0;
+            for (int i = 0; i < 2; i++) a[S][i] = *(const pf4 *)(da + (size_t)(32 * i) * g.P);
+            const float *xb = xp + (size_t)n * g.img + (size_t)ho * g.pitch + wo0;
 #pragma unroll
-        for (int t = 0; t < 5; t++) b[t] = *(const pf4_u *)(xb + coff[t]);
-    };
-    auto mul = [&](const pf4 (&a)[2], const pf4 (&b)[5]) {
+            for (int t = 0; t < 5; t++) b[S][t] = *(const pf4_u *)(xb + coff[t]);
+        };
+        auto mul = [&](auto set_tag) {
+            constexpr int S = decltype(set_tag)::value;
 #pragma unroll
-        for (int e = 0; e < 4; e++)
+            for (int e = 0; e < 4; e++)
 #pragma unroll
-            for (int i = 0; i < 2; i++)
+                for (int i = 0; i < 2; i++)
 #pragma unroll
-                for (int t = 0; t < 5; t++) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[t][e], acc[i][t], 0, 0, 0);
-    };
-    pf4 a0[2], a1[2], b0[5], b1[5];
-    const int per = (nchunks + nw - 1) / nw, c_end = min(nchunks, (gw + 1) * per);
-    int chunk = gw * per;
-    if (chunk < c_end) load(chunk, a0, b0);
-    for (; chunk + 1 < c_end; chunk += 2) {
-        load(chunk + 1, a1, b1);
-        mul(a0, b0);
-        if (chunk + 2 < c_end) load(chunk + 2, a0, b0);
-        mul(a1, b1);
+                    for (int t = 0; t < 5; t++) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S][i][e], b[S][t][e], acc[i][t], 0, 0, 0);
+        };
+        st_static_for<NS - 1>([&](auto J) { load(c_beg + decltype(J)::value, J); });
+        for (int chunk = c_beg; chunk < c_end; chunk += NS)
+            st_static_for<NS>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                load(chunk + j + NS - 1, std::integral_constant<int, (j + NS - 1) % NS>{});
+                if (chunk + j < c_end) mul(J);
+            });
     }
-    if (chunk < c_end) mul(a0, b0);
     float *o = part + (size_t)gw * (ST_K * ST_COLS);
 #pragma unroll
     for (int i = 0; i < 2; i++)
@@ -425,8 +441,8 @@ static int st_geometry(StArgs &g, int N, int H) {
     g.fdWo = make_fastdiv(g.Wo);
     return 0;
 }
-static int st_waves(long units) { // waves that share the work: at most ST_WAVES, a multiple of 4
-    long w = units < ST_WAVES ? units : ST_WAVES;
+static int st_waves(long units, int cap = ST_WAVES) { // waves that share the work: at most cap, a multiple of 4
+    long w = units < cap ? units : cap;
     w = (w + 3) / 4 * 4;
     return (int)w;
 }
@@ -503,7 +519,7 @@ int mid_stem_wgrad_f32(mid_stream s, const void *xp, const float *dy, float *dw,
     if (scratch_floats < mid_stem_bf16_part_floats(N, H)) { mi_record_error("mid_stem_wgrad_f32", "workspace too small"); return -3; }
     const int nchunks = N * (g.P / 8);
     g.fdTpi = make_fastdiv(g.P / 8);
-    const int waves = st_waves(nchunks);
+    const int waves = st_waves(nchunks, ST_WAVES / 2); /* one wave per SIMD (register ring) */
     mi_prof_begin(st, MI_FAM_WGRAD, 2.0 * N * g.P * ST_K * 147.0, 4.0 * ((double)N * ST_K * g.P) + 4.0 * N * g.img);
     hipLaunchKernelGGL(st32_wgrad_kernel, dim3(waves / 4), dim3(256), 0, st, (const float *)xp, dy, scratch, g, nchunks);
     hipLaunchKernelGGL(st_wgrad_reduce_kernel, dim3((ST_K * 147 + 63) / 64), dim3(256), 0, st, scratch, dw, waves);
@@ -518,7 +534,7 @@ int mid_stem_wgrad_bf16(mid_stream s, const void *xp, const float *dy, float *dw
     if (scratch_floats < mid_stem_bf16_part_floats(N, H)) { mi_record_error("mid_stem_wgrad_bf16", "workspace too small"); return -3; }
     const int nchunks = N * (g.P / 16);
     g.fdTpi = make_fastdiv(g.P / 16);
-    const int waves = st_waves(nchunks);
+    const int waves = st_waves(nchunks, ST_WAVES / 2); /* one wave per SIMD (register ring) */
     mi_prof_begin(st, MI_FAM_WGRAD, 2.0 * N * g.P * ST_K * 147.0, 4.0 * ((double)N * ST_K * g.P) + 2.0 * N * g.img);
     hipLaunchKernelGGL(st_wgrad_kernel, dim3(waves / 4), dim3(256), 0, st, (const u16 *)xp, dy, scratch, g, nchunks);
     hipLaunchKernelGGL(st_wgrad_reduce_kernel, dim3((ST_K * 147 + 63) / 64), dim3(256), 0, st, scratch, dw, waves);
