@@ -181,7 +181,10 @@ __device__ __forceinline__ float bn_y(float xh, float g, float b) { return fmaf(
 
 // TX: storage type of the convolution output x; TA: of the activation-side tensors (y, residual).  The full-store extras
 // (x_hat, BN output) exist in fp32 only.
-template <typename TX, typename TA, int V>
+// STR: the plane size is not a multiple of V (7x7 planes: 49), so a vector of V consecutive elements may run over into the NEXT
+// channel's plane (V <= P: at most one boundary): elements from `nfirst` on take that channel's scalars.  The scalar kernels this
+// replaces ran the 7x7 stage at a quarter of the bandwidth (2.5 ms of the fp32 step).
+template <typename TX, typename TA, int V, bool STR>
 __global__ void __launch_bounds__(256)
 bn_apply_kernel(const TX *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
                 const float *__restrict__ means, const float *__restrict__ vars, const TA *__restrict__ residual,
@@ -192,12 +195,21 @@ bn_apply_kernel(const TX *__restrict__ x, const float *__restrict__ gamma, const
         const size_t e = i * V;
         const uint32_t plane = fd_div((uint32_t)e, fdP);
         const uint32_t c = plane - fd_div(plane, fdC) * C;
-        const float mean = means[c], sd = sqrtf(vars[c] + eps), g = gamma[c], b = beta[c];
+        const float mean0 = means[c], sd0 = sqrtf(vars[c] + eps), g0 = gamma[c], b0 = beta[c];
+        int nfirst = V;
+        float mean1 = mean0, sd1 = sd0, g1 = g0, b1 = b0;
+        if (STR) {
+            nfirst = min(V, P - (int)((uint32_t)e - plane * (uint32_t)P));
+            const uint32_t c1 = c + 1 == (uint32_t)C ? 0u : c + 1;
+            mean1 = means[c1]; sd1 = sqrtf(vars[c1] + eps); g1 = gamma[c1]; b1 = beta[c1];
+        }
         float v[V], r[V], xh[V], nv[V];
         VecIO<TX, V>::load(x + e, v);
         if (residual) VecIO<TA, V>::load(residual + e, r);
 #pragma unroll
         for (int q = 0; q < V; q++) {
+            const bool nx = STR && q >= nfirst;
+            const float mean = nx ? mean1 : mean0, sd = nx ? sd1 : sd0, g = nx ? g1 : g0, b = nx ? b1 : b0;
             xh[q] = bn_xhat(v[q], mean, sd);
             nv[q] = bn_y(xh[q], g, b);
             float o = nv[q];
@@ -342,7 +354,7 @@ bn_bwd_finalize_kernel(float *__restrict__ partial, int nsplit, int C, float *__
     if (lane == 0) { dbeta[c] = s1; dgamma[c] = s2; }
 }
 
-template <int MASK, typename TX, typename TA, int V>
+template <int MASK, typename TX, typename TA, int V, bool STR>
 __global__ void __launch_bounds__(256)
 bn_bwd_apply_kernel(const TX *__restrict__ x, const TA *__restrict__ dy, const TA *__restrict__ mask_src,
                     const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ means,
@@ -353,14 +365,25 @@ bn_bwd_apply_kernel(const TX *__restrict__ x, const TA *__restrict__ dy, const T
         const size_t e = i * V;
         const uint32_t plane = fd_div((uint32_t)e, fdP);
         const uint32_t c = plane - fd_div(plane, fdC) * C;
-        const float mean = means[c], sd = sqrtf(vars[c] + eps), g = gamma[c], b = beta[c];
-        const float k1 = dbeta[c] * inv_m, k2 = dgamma[c] * inv_m, scale = g / sd;
+        const float mean0 = means[c], sd0 = sqrtf(vars[c] + eps), g0 = gamma[c], b0 = beta[c];
+        const float k10 = dbeta[c] * inv_m, k20 = dgamma[c] * inv_m, scale0 = g0 / sd0;
+        int nfirst = V;
+        float mean1 = mean0, sd1 = sd0, g1 = g0, b1 = b0, k11 = k10, k21 = k20, scale1 = scale0;
+        if (STR) { // (see bn_apply_kernel)
+            nfirst = min(V, P - (int)((uint32_t)e - plane * (uint32_t)P));
+            const uint32_t c1 = c + 1 == (uint32_t)C ? 0u : c + 1;
+            mean1 = means[c1]; sd1 = sqrtf(vars[c1] + eps); g1 = gamma[c1]; b1 = beta[c1];
+            k11 = dbeta[c1] * inv_m; k21 = dgamma[c1] * inv_m; scale1 = g1 / sd1;
+        }
         float xv[V], dv[V], mv[V];
         VecIO<TX, V>::load(x + e, xv);
         VecIO<TA, V>::load(dy + e, dv);
         if (MASK == 2) VecIO<TA, V>::load(mask_src + e, mv);
 #pragma unroll
         for (int q = 0; q < V; q++) {
+            const bool nx = STR && q >= nfirst;
+            const float mean = nx ? mean1 : mean0, sd = nx ? sd1 : sd0, g = nx ? g1 : g0, b = nx ? b1 : b0;
+            const float k1 = nx ? k11 : k10, k2 = nx ? k21 : k20, scale = nx ? scale1 : scale0;
             const float xh = bn_xhat(xv[q], mean, sd);
             bool on = true;
             if (MASK == 1) on = bn_y(xh, g, b) > 0.f;
@@ -430,6 +453,24 @@ static bool bn_pair_ok(int x_dt, int a_dt) {
         else { if (vec == 8) { BODY(float, bf16_t, 8); } else if (vec == 4) { BODY(float, bf16_t, 4); } else { BODY(float, bf16_t, 1); } } \
     } while (0)
 
+// elementwise kernels: the widest vector also where the plane size is not a multiple of it (STR), as long as the tensor is and a
+// plane holds at least one vector.  BODY(TX, TA, V, STR)
+static int bn_vec_ew(int x_dt, int a_dt, int P, size_t total, bool *str) {
+    int vec = bn_vec(x_dt, a_dt, P);
+    *str = false;
+    const int vmax = (x_dt == MID_F32 && a_dt == MID_F32) ? 4 : 8;
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("RESNET_MI_BN_STRADDLE"); on = e ? atoi(e) : 1; }
+    if (on && vec == 1 && P >= vmax && total % vmax == 0) { vec = vmax; *str = true; }
+    return vec;
+}
+#define BN_DISPATCH_EW(BODY)                                                                         \
+    do {                                                                                             \
+        if (x_dt == MID_F32 && a_dt == MID_F32) { if (str) { BODY(float, float, 4, true); } else if (vec == 4) { BODY(float, float, 4, false); } else { BODY(float, float, 1, false); } } \
+        else if (x_dt == MID_BF16) { if (str) { BODY(bf16_t, bf16_t, 8, true); } else if (vec == 8) { BODY(bf16_t, bf16_t, 8, false); } else if (vec == 4) { BODY(bf16_t, bf16_t, 4, false); } else { BODY(bf16_t, bf16_t, 1, false); } } \
+        else { if (str) { BODY(float, bf16_t, 8, true); } else if (vec == 8) { BODY(float, bf16_t, 8, false); } else if (vec == 4) { BODY(float, bf16_t, 4, false); } else { BODY(float, bf16_t, 1, false); } } \
+    } while (0)
+
 static size_t dt_bytes(int dt) { return dt == MID_BF16 ? 2 : 4; }
 static struct { void *comm; int world, force; float *tmp; size_t tmp_floats; } g_bn_sync;
 
@@ -448,11 +489,12 @@ static int bn_fwd_apply(hipStream_t st, const void *x, int x_dt, const float *ga
                         int P, float eps, int relu) {
     const size_t total = (size_t)N * C * P;
     const FastDiv fdP = make_fastdiv(P), fdC = make_fastdiv(C);
-    const int vec = bn_vec(x_dt, a_dt, P);
-#define APPLY(TX, TA, V)                                                                                                   \
-    hipLaunchKernelGGL((bn_apply_kernel<TX, TA, V>), dim3(ew_blocks(total / V)), dim3(256), 0, st, (const TX *)x, gamma, beta, \
+    bool str;
+    const int vec = bn_vec_ew(x_dt, a_dt, P, total, &str);
+#define APPLY(TX, TA, V, STR)                                                                                              \
+    hipLaunchKernelGGL((bn_apply_kernel<TX, TA, V, STR>), dim3(ew_blocks(total / V)), dim3(256), 0, st, (const TX *)x, gamma, beta, \
                        means, vars, (const TA *)residual, (TA *)y, xhat_out, norm_out, C, P, fdP, fdC, total, eps, relu)
-    BN_DISPATCH(APPLY);
+    BN_DISPATCH_EW(APPLY);
 #undef APPLY
     MI_LAUNCH_CHECK("bn_apply_kernel");
     return 0;
@@ -598,17 +640,21 @@ static int bn_bwd_impl(hipStream_t st, float *ws, const void *x, int x_dt, const
         dg_apply = tmp; db_apply = tmp + C;              // sums over every replica's samples
         inv_m = 1.0f / ((float)g_bn_sync.world * (float)((size_t)N * P));
     }
-    dim3 g2(ew_blocks(total / vec));
     const void *dy_apply = mask_mode == 3 ? gated_out : dy; // mode 3: the gated dy is already there, no mask needed
-#define BWD_APPLY_M(M_, TX, TA, V)                                                                                             \
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<M_, TX, TA, V>), g2, block, 0, st, (const TX *)x, (const TA *)dy_apply, (const TA *)mask_src, \
+    {
+    bool str;
+    const int vec = bn_vec_ew(x_dt, a_dt, P, total, &str); // (shadows the reduction pass's vector width)
+    dim3 g2(ew_blocks(total / vec));
+#define BWD_APPLY_M(M_, TX, TA, V, STR)                                                                                        \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<M_, TX, TA, V, STR>), g2, block, 0, st, (const TX *)x, (const TA *)dy_apply, (const TA *)mask_src, \
                        gamma, beta, means, vars, dg_apply, db_apply, (TX *)dx, C, P, fdP, fdC, total, inv_m, eps)
-#define BWD_A0(TX, TA, V) BWD_APPLY_M(0, TX, TA, V)
-#define BWD_A1(TX, TA, V) BWD_APPLY_M(1, TX, TA, V)
-#define BWD_A2(TX, TA, V) BWD_APPLY_M(2, TX, TA, V)
-    if (mask_mode == 0 || mask_mode == 3) BN_DISPATCH(BWD_A0);
-    else if (mask_mode == 1) BN_DISPATCH(BWD_A1);
-    else BN_DISPATCH(BWD_A2);
+#define BWD_A0(TX, TA, V, STR) BWD_APPLY_M(0, TX, TA, V, STR)
+#define BWD_A1(TX, TA, V, STR) BWD_APPLY_M(1, TX, TA, V, STR)
+#define BWD_A2(TX, TA, V, STR) BWD_APPLY_M(2, TX, TA, V, STR)
+    if (mask_mode == 0 || mask_mode == 3) BN_DISPATCH_EW(BWD_A0);
+    else if (mask_mode == 1) BN_DISPATCH_EW(BWD_A1);
+    else BN_DISPATCH_EW(BWD_A2);
+    }
 #undef BWD_A0
 #undef BWD_A1
 #undef BWD_A2
