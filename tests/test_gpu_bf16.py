@@ -349,10 +349,12 @@ def _make(dims, batch, oracle, dtype, policy=None):
 BLOCK_FWD = ["reduction_applied", "reduction_activated", "spatial_applied", "spatial_activated", "expanded_applied", "output_activated"]
 
 
-@pytest.mark.parametrize("cfg", ["C1", "C1S", "C1S_batch5", "C4I"])
+@pytest.mark.parametrize("cfg", ["C1", "C1S", "C1S_batch5", "C4I", "C1_in48"])
 def test_training_step_bf16_vs_fp32_oracle(oracle, cfg):
     import torch_ref
-    dims, batch = (synth.C1_DIMS, synth.C1_BATCH) if cfg == "C1" else (synth.C4I_DIMS, 4) if cfg == "C4I" else (synth.C1S_DIMS, 5 if cfg.endswith("5") else 4)
+    # in48: the stem stays on the fp32 VALU kernels (24 pixels per output row), the block runs on 12x12 planes
+    dims, batch = (synth.C1_DIMS, synth.C1_BATCH) if cfg == "C1" else (synth.C4I_DIMS, 4) if cfg == "C4I" else \
+        (synth.resnet_dims(input=48, n_conv_blocks=1, reductions=(), final_depth=256), 3) if cfg == "C1_in48" else (synth.C1S_DIMS, 5 if cfg.endswith("5") else 4)
     net, tr = _make(dims, batch, oracle, BF16)
     worst = {"act": 0.0, "grad": 0.0, "loss": 0.0, "ratio": 0.0}
     try:

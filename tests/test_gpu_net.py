@@ -68,10 +68,13 @@ BLOCK_FWD = ["reduction_applied", "reduction_activated", "spatial_applied", "spa
              "output_activated"]
 
 
-@pytest.mark.parametrize("cfg", ["C1", "C1S", "C1S_batch5"])
+@pytest.mark.parametrize("cfg", ["C1", "C1S", "C1S_batch5", "C1_in48"])
 def test_training_step_parity(oracle, oracle64, cfg):
     # batch 5: column counts of every layer are odd multiples (ragged last tiles, images straddling tiles) in a whole step
-    dims, batch = (synth.C1_DIMS, synth.C1_BATCH) if cfg == "C1" else (synth.C1S_DIMS, 5 if cfg.endswith("5") else 4)
+    # in48: a 48x48 input (24x24 stem output: not a multiple of 16 pixels per row) keeps the stem on the VALU kernels, and gives
+    # 12x12 planes (144 pixels) to the block
+    dims, batch = (synth.C1_DIMS, synth.C1_BATCH) if cfg == "C1" else (synth.resnet_dims(input=48, n_conv_blocks=1, reductions=(), final_depth=256), 3) \
+        if cfg == "C1_in48" else (synth.C1S_DIMS, 5 if cfg.endswith("5") else 4)
     net, tr = _make(dims, batch, oracle)
     from oracle.oracle_py import OracleNet
     ref64 = OracleNet(oracle64, dims, batch)  # double-accumulation twin: arbiter for ReLU gates that sit on a rounding error
