@@ -92,9 +92,33 @@ st_wt_kernel(const float *__restrict__ w, u16 *__restrict__ wf) {
     wf[i] = mi_f2bf(v);
 }
 
+// Batch-norm statistics of the stem's output, taken from the forward kernels' accumulators (what kernels_igemm*.hip do for every
+// other convolution): a lane holds 16 pixels of ONE channel per accumulator, so it keeps a running (count, sum of d, sum of d^2)
+// with d = value - its own first value; at the end the two half-waves are Chan-merged and the wave writes one partial row
+// (count, mean, M2) per channel -- three planes [waves][64], the format bn_parts_merge_kernel reads.
+struct StStat { float s0, sd, sq; int n; };
+__device__ __forceinline__ void st_stat_add(StStat &a, const f32x16 &v) {
+    if (a.n == 0) a.s0 = v[0];
+#pragma unroll
+    for (int r = 0; r < 16; r++) { const float d = v[r] - a.s0; a.sd += d; a.sq = fmaf(d, d, a.sq); }
+    a.n += 16;
+}
+__device__ __forceinline__ void st_stat_write(const StStat &a, float *__restrict__ part, int np, int row, int ch, int kh) {
+    // this half-wave's (n, mean, M2), merged with the other half's (same channel, other pixels)
+    const float n = (float)a.n, inv = a.n ? 1.0f / n : 0.f;
+    const float mean = a.n ? a.s0 + a.sd * inv : 0.f, m2 = fmaxf(a.sq - a.sd * a.sd * inv, 0.f);
+    const float n2 = __shfl_xor(n, 32, 64), mean2 = __shfl_xor(mean, 32, 64), m22 = __shfl_xor(m2, 32, 64);
+    const float nt = n + n2, dl = mean2 - mean;
+    const float mt = nt > 0.f ? mean + dl * (n2 / nt) : 0.f, m2t = nt > 0.f ? m2 + m22 + dl * dl * (n * n2 / nt) : 0.f;
+    if (kh == 0) {
+        const size_t o = (size_t)row * ST_K + ch, plane = (size_t)np * ST_K;
+        part[o] = nt; part[plane + o] = mt; part[2 * plane + o] = m2t;
+    }
+}
+
 // ---- forward ----
 __global__ void __launch_bounds__(256)
-st_fwd_kernel(const u16 *__restrict__ xp, const u16 *__restrict__ wf, float *__restrict__ y, const StArgs g, int ntiles) {
+st_fwd_kernel(const u16 *__restrict__ xp, const u16 *__restrict__ wf, float *__restrict__ y, const StArgs g, int ntiles, float *__restrict__ bn_part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char st_smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
@@ -123,6 +147,7 @@ st_fwd_kernel(const u16 *__restrict__ xp, const u16 *__restrict__ wf, float *__r
     // a wave walks a CONTIGUOUS range of tiles: its reads of the planes and its 64 output rows are sequential streams
     const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
     const int per = (ntiles + nw - 1) / nw, t_end = min(ntiles, (gw + 1) * per);
+    StStat stat[2] = {{0.f, 0.f, 0.f, 0}, {0.f, 0.f, 0.f, 0}};
     for (int tile = gw * per; tile < t_end; tile++) {
         const uint32_t n = fd_div((uint32_t)tile, g.fdTpi);
         const uint32_t p0 = ((uint32_t)tile - n * g.fdTpi.d) * 32u;
@@ -151,6 +176,7 @@ st_fwd_kernel(const u16 *__restrict__ xp, const u16 *__restrict__ wf, float *__r
             for (int t = 0; t < 2; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8 *)&av, wfr[t][s], acc[t], 0, 0, 0);
         }
         // accumulator t: rows = pixels (r & 3) + 8 (r >> 2) + 4 kh, column = channel l31 + 32 t
+        if (bn_part) { st_stat_add(stat[0], acc[0]); st_stat_add(stat[1], acc[1]); }
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll
@@ -168,6 +194,7 @@ st_fwd_kernel(const u16 *__restrict__ xp, const u16 *__restrict__ wf, float *__r
             if (ST_ABL != 1 || v[0] == 1.2345f) *(pf4 *)(dst + (size_t)ch * g.P) = v;
         }
     }
+    if (bn_part) { st_stat_write(stat[0], bn_part, nw, gw, l31, kh); st_stat_write(stat[1], bn_part, nw, gw, 32 + l31, kh); }
 }
 
 // ---- weight gradient: per-wave partials [wave][64][160] ----
@@ -305,7 +332,7 @@ st32_wt_kernel(const float *__restrict__ w, float *__restrict__ wl) {
     wl[idx] = s >= 0 ? w[(size_t)ch * 147 + gq * 7 + s] : 0.f;
 }
 __global__ void __launch_bounds__(256)
-st32_fwd_kernel(const float *__restrict__ xp, const float *__restrict__ wl, float *__restrict__ y, const StArgs g, int ntiles) {
+st32_fwd_kernel(const float *__restrict__ xp, const float *__restrict__ wl, float *__restrict__ y, const StArgs g, int ntiles, float *__restrict__ bn_part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char st_smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
@@ -324,6 +351,7 @@ st32_fwd_kernel(const float *__restrict__ xp, const float *__restrict__ wl, floa
     }
     const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
     const int per = (ntiles + nw - 1) / nw, t_end = min(ntiles, (gw + 1) * per);
+    StStat stat[2] = {{0.f, 0.f, 0.f, 0}, {0.f, 0.f, 0.f, 0}};
     for (int tile = gw * per; tile < t_end; tile++) {
         const uint32_t n = fd_div((uint32_t)tile, g.fdTpi);
         const uint32_t p0 = ((uint32_t)tile - n * g.fdTpi.d) * 32u;
@@ -348,6 +376,7 @@ st32_fwd_kernel(const float *__restrict__ xp, const float *__restrict__ wl, floa
 #pragma unroll
                 for (int t = 0; t < 2; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gq][i], wp[32 * t], acc[t], 0, 0, 0);
             }
+        if (bn_part) { st_stat_add(stat[0], acc[0]); st_stat_add(stat[1], acc[1]); }
 #pragma unroll
         for (int t = 0; t < 2; t++)
 #pragma unroll
@@ -364,6 +393,7 @@ st32_fwd_kernel(const float *__restrict__ xp, const float *__restrict__ wl, floa
             *(pf4 *)(dst + (size_t)ch * g.P) = v;
         }
     }
+    if (bn_part) { st_stat_write(stat[0], bn_part, nw, gw, l31, kh); st_stat_write(stat[1], bn_part, nw, gw, 32 + l31, kh); }
 }
 // NS register sets of operands in a ring: the loads of chunks j + 1 .. j + NS - 1 are in flight while chunk j is multiplied (one
 // wave per SIMD; a chunk's 40 MFMAs are 640 cycles, HBM latency several thousand).  Every load is unconditional -- past the
@@ -441,6 +471,14 @@ static int st_geometry(StArgs &g, int N, int H) {
     g.fdWo = make_fastdiv(g.Wo);
     return 0;
 }
+// where the forward leaves its statistics partials (one row per wave), or NULL
+static float *st_parts(mid_bn_parts *parts, int waves) {
+    if (!parts) return nullptr;
+    parts->nparts = 0;
+    if (!parts->buf || parts->floats < (size_t)3 * waves * ST_K) return nullptr;
+    parts->nparts = waves;
+    return parts->buf;
+}
 static int st_waves(long units, int cap = ST_WAVES) { // waves that share the work: at most cap, a multiple of 4
     long w = units < cap ? units : cap;
     w = (w + 3) / 4 * 4;
@@ -462,7 +500,7 @@ size_t mid_stem_bf16_part_floats(int N, int H) {
 }
 /* y (fp32) = conv7x7s2(bf16(x), bf16(w)); leaves the padded parity planes of x in xp for the weight gradient */
 int mid_stem_fwd_bf16(mid_stream s, const float *x, const float *w, float *y, void *xp, size_t xp_bytes, float *scratch, size_t scratch_floats,
-                      int N, int H) {
+                      int N, int H, mid_bn_parts *parts) {
     hipStream_t st = (hipStream_t)s;
     StArgs g; st_geometry(g, N, H);
     if (xp_bytes < mid_stem_bf16_xp_bytes(N, H) || scratch_floats < mid_stem_bf16_part_floats(N, H)) { mi_record_error("mid_stem_fwd_bf16", "workspace too small"); return -3; }
@@ -475,7 +513,8 @@ int mid_stem_fwd_bf16(mid_stream s, const float *x, const float *w, float *y, vo
     const int ntiles = N * (g.P / 32);
     g.fdTpi = make_fastdiv(g.P / 32);
     const int waves = st_waves(ntiles);
-    hipLaunchKernelGGL(st_fwd_kernel, dim3(waves / 4), dim3(256), 4 * 64 * (32 * 4 + 16), st, (const u16 *)xp, wf, y, g, ntiles);
+    float *bn_part = st_parts(parts, waves);
+    hipLaunchKernelGGL(st_fwd_kernel, dim3(waves / 4), dim3(256), 4 * 64 * (32 * 4 + 16), st, (const u16 *)xp, wf, y, g, ntiles, bn_part);
     mi_prof_end(st);
     MI_LAUNCH_CHECK("st_fwd_kernel");
     return 0;
@@ -486,7 +525,7 @@ size_t mid_stem_f32_xp_bytes(int N, int H) {
     return (size_t)N * g.img * 4 + 64;
 }
 int mid_stem_fwd_f32(mid_stream s, const float *x, const float *w, float *y, void *xp, size_t xp_bytes, float *scratch, size_t scratch_floats,
-                     int N, int H) {
+                     int N, int H, mid_bn_parts *parts) {
     hipStream_t st = (hipStream_t)s;
     StArgs g; st_geometry(g, N, H);
     if (xp_bytes < mid_stem_f32_xp_bytes(N, H) || scratch_floats < mid_stem_bf16_part_floats(N, H)) { mi_record_error("mid_stem_fwd_f32", "workspace too small"); return -3; }
@@ -508,7 +547,8 @@ int mid_stem_fwd_f32(mid_stream s, const float *x, const float *w, float *y, voi
         }
         attr_set = 1;
     }
-    hipLaunchKernelGGL(st32_fwd_kernel, dim3(waves / 4), dim3(256), lds, st, (const float *)xp, wl, y, g, ntiles);
+    float *bn_part = st_parts(parts, waves);
+    hipLaunchKernelGGL(st32_fwd_kernel, dim3(waves / 4), dim3(256), lds, st, (const float *)xp, wl, y, g, ntiles, bn_part);
     mi_prof_end(st);
     MI_LAUNCH_CHECK("st32_fwd_kernel");
     return 0;

@@ -702,12 +702,11 @@ static void unit_fwd(Train_ResNet *t, const float *in, const float *w, const Bat
     mid_bn_parts *parts = (c->fuse_bn_stats || bf) ? &c->bn_parts : NULL;
     c->ws.pre_fwd = we ? we->fwd : NULL; /* re-laid at the start of this forward pass */
     if (stem && c->stem_scratch && c->dtype == MID_F32) {
-        if (parts) parts->nparts = 0; /* (no statistics from this kernel: BN takes its own pass) */
-        ck(mid_stem_fwd_f32(G.compute, in, w, conv_out, c->stem_xp, c->stem_xp_bytes, c->stem_scratch, c->stem_scratch_floats, N, H),
+        ck(mid_stem_fwd_f32(G.compute, in, w, conv_out, c->stem_xp, c->stem_xp_bytes, c->stem_scratch, c->stem_scratch_floats, N, H, parts),
            "stem convolution forward (fp32 matrix cores)");
     } else if (stem && c->stem_scratch) {
-        if (parts) parts->nparts = 0; /* (no statistics from this kernel: BN takes its own pass) */
-        ck(mid_stem_fwd_bf16(G.compute, in, w, conv_out, c->stem_xp, c->stem_xp_bytes, c->stem_scratch, c->stem_scratch_floats, N, H),
+        parts = &c->bn_parts; /* (the stem's tensors are fp32 here, but its statistics still come from the kernel's accumulators) */
+        ck(mid_stem_fwd_bf16(G.compute, in, w, conv_out, c->stem_xp, c->stem_xp_bytes, c->stem_scratch, c->stem_scratch_floats, N, H, parts),
            "stem convolution forward (bf16 operands)");
     } else if (bf) ck(mid_conv_fwd_bf16(G.compute, &c->ws, in, w, conv_out, N, C, H, K, k, stride, parts), "convolution forward (bf16)");
     else ck(mid_conv_fwd_stats(G.compute, &c->ws, in, w, conv_out, N, C, H, K, k, stride, parts), "convolution forward");
