@@ -7,6 +7,9 @@
  *   gcc -O2 -Iinclude examples/resnet_main.c -Lresnet_amd -lresnet_mi -lm -Wl,-rpath,$PWD/resnet_amd -o ResNetMI
  *   ./ResNetMI --iters 20 --batch 64                       synthetic data, reference-defined ResNet-50
  *   ./ResNetMI --shards /data/train_data_shards/nchw --layout nchw --shard-images 32768 --batch 256
+ *   ./ResNetMI --labels-file id_to_label_mapping.txt --synsets-file id_to_synset_mapping.txt --counts-file id_to_img_count_mapping.txt
+ *              the class metadata of resnet.cu:3236-3242: iterations per epoch = ceil(sum of the class counts / batch) (:3309)
+ *              unless --iters says otherwise
  */
 #include <math.h>
 #include <stdio.h>
@@ -24,7 +27,7 @@ int main(int argc, char **argv) {
     const int INPUT_DIM = atoi(opt(argc, argv, "--input", "224"));
     const int N_CONV_BLOCKS = atoi(opt(argc, argv, "--blocks", "16"));
     const int BATCH_SIZE = atoi(opt(argc, argv, "--batch", "32"));          /* resnet.cu:3279 */
-    const int iters = atoi(opt(argc, argv, "--iters", "10"));                /* iterations per epoch (reference: ceil(total_images / BATCH_SIZE), :3308) */
+    int iters = atoi(opt(argc, argv, "--iters", "-1"));                      /* iterations per epoch; default: from the class counts (below), else 10 */
     const int N_EPOCHS = atoi(opt(argc, argv, "--epochs", "1"));              /* resnet.cu:3293 (40) */
     const float LEARNING_RATE = (float)atof(opt(argc, argv, "--lr", "0.0001")); /* resnet.cu:3286-3291 */
     const float WEIGHT_DECAY = (float)atof(opt(argc, argv, "--wd", "0"));
@@ -35,6 +38,18 @@ int main(int argc, char **argv) {
     const char *dump_root = opt(argc, argv, "--dump-root", NULL);
     const char *loss_log = opt(argc, argv, "--loss-log", "avg_loss_log.txt");
     const int resume_id = atoi(opt(argc, argv, "--resume", "-1"));           /* LOAD_FROM_DUMP_ID, resnet.cu:3299 */
+
+    /* GETTING CLASS METADATA (resnet.cu:3236-3242): total_images = sum of the per-class image counts */
+    char *labels_file = (char *)opt(argc, argv, "--labels-file", NULL), *synsets_file = (char *)opt(argc, argv, "--synsets-file", NULL),
+         *counts_file = (char *)opt(argc, argv, "--counts-file", NULL);
+    Class_Metadata *class_metadata = NULL;
+    int total_images = 0;
+    if (labels_file && synsets_file && counts_file) {
+        class_metadata = populate_class_info(labels_file, synsets_file, counts_file, N_CLASSES);
+        for (int i = 0; i < N_CLASSES; i++) total_images += class_metadata->counts[i];
+        printf("class metadata: %d classes, %d images\n", N_CLASSES, total_images);
+    }
+    if (iters < 0) iters = class_metadata ? (int)ceil((float)total_images / BATCH_SIZE) : 10; /* resnet.cu:3309 */
 
     if (mi_device_count() < 1) { fprintf(stderr, "no HIP device\n"); return 1; }
     int *reductions = (int *)calloc(N_CONV_BLOCKS > 0 ? N_CONV_BLOCKS : 1, sizeof(int));
@@ -52,6 +67,7 @@ int main(int argc, char **argv) {
     if (resume_id != -1) { overwrite_trainer_hyperparams(trainer, resume_id, "my_custom"); overwrite_model_params(trainer, resume_id, "my_custom"); }
 
     FILE *loss_file = fopen(loss_log, "w");
+    printf("iterations per epoch: %d\n", iters);
     /* the epoch loop of resnet.cu:3327-3421, including the restart position after a resume (:3324-3325) */
     const int iterations_per_epoch = iters;
     const float total_images_per_epoch = (float)BATCH_SIZE * iterations_per_epoch;
@@ -60,7 +76,7 @@ int main(int argc, char **argv) {
     for (int epoch = trainer->cur_epoch; epoch < N_EPOCHS && !stop; epoch++) {
         float epoch_loss = 0, epoch_n_wrong = 0;
         for (int iter = cur_iter_in_epoch; iter < iterations_per_epoch; iter++) {
-            load_new_batch(trainer, NULL, trainer->cur_batch);
+            load_new_batch(trainer, class_metadata, trainer->cur_batch);
             if (mi_batch_last_status(trainer->cur_batch)) { fprintf(stderr, "data source exhausted\n"); stop = 1; break; }
             forward_pass(trainer);
             const float *pred = trainer->forward_buffer->pred_cpu;

@@ -351,6 +351,17 @@ void mi_clear_error(void);
  * launch; it is read at the next forward_pass, or here (waits for the device; dumps id 99999999 and exits like the reference
  * when set).  Returns 0 when clean. */
 int mi_trainer_check_errors(Train_ResNet *t);
+/* the locations[] index the last NaN / Inf report named -- "ERROR: nan or inf found at location: %d" (resnet.cu:2896; the
+ * reference walks locations[] from the last to the first, :2952, so the highest offending index is the one it prints); -1 = none.
+ * mi_trainer_set_nan_exit(t, 0): a report no longer ends the process (the reference's exit(1), :2899) but comes back through
+ * mi_trainer_check_errors / mi_trainer_nan_location -- for tests. */
+int mi_trainer_nan_location(const Train_ResNet *t);
+void mi_trainer_set_nan_exit(Train_ResNet *t, int on);
+/* test aid: the device-side merge of cross-replica batch norm (mi_dp_enable_sync_bn) on R replicas held by ONE process -- the
+ * kernels the trainer launches around its collectives, with the all-reduce replaced by a sum over the R supplied buffers.
+ * Device pointers [R][C]: means / vars (per-replica in, merged out), dgamma / dbeta (per-replica sums in, gradient-arena values
+ * out = sum / R), sums_out [R][2C] (the sums each replica's dx formula sees) or NULL.  Either pair may be NULL. */
+int mi_debug_bn_merge(int R, int C, float *means, float *vars, float *dgamma, float *dbeta, float *sums_out);
 /* the end-of-epoch bookkeeping of the reference's main() (resnet.cu:3410-3421) */
 void mi_trainer_end_epoch(Train_ResNet *t, float epoch_loss, float epoch_n_wrong, float total_images_per_epoch);
 /* host-only (no GPU needed): the gradient buckets the data-parallel path cuts for a network -- float offsets [from, to) into

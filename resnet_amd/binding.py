@@ -180,6 +180,9 @@ PROTOTYPES = {
     "mi_clear_error": (None, []),
     "mi_trainer_check_errors": (_i, [_T]),
     "mi_trainer_end_epoch": (None, [_T, _f, _f, _f]),
+    "mi_trainer_nan_location": (_i, [_T]),
+    "mi_trainer_set_nan_exit": (None, [_T, _i]),
+    "mi_debug_bn_merge": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp]),
     "mi_debug_dp_plan": (_i, [C.POINTER(Dims), _sz, _vp, _vp, _i]),
     "mi_debug_arena_floats": (_sz, [C.POINTER(Dims)]),
     "mi_debug_last_buckets": (_i, [_T, _vp, _vp, _i]),

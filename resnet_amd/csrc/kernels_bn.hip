@@ -436,6 +436,15 @@ __global__ void bn_sync_unpack(const float *__restrict__ in, float *__restrict__
     if (c < C) { a[c] = in[c] * inv_world; b[c] = in[C + c] * inv_world; }
 }
 
+// test aid (mid_bn_debug_merge): what an all-reduce SUM over R replicas delivers to each of them, for R buffers of one process
+__global__ void bn_sync_emul_allreduce(float *__restrict__ bufs, int R, size_t stride, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int r = 0; r < R; r++) s += bufs[(size_t)r * stride + i];
+    for (int r = 0; r < R; r++) bufs[(size_t)r * stride + i] = s;
+}
+
 // dtype codes of the storage types: MID_F32 / MID_BF16 (mi_device.h).  Supported (x, activation) pairs: (f32, f32) the
 // reference's path, (bf16, bf16) the bf16-activation path, (f32, bf16) its stem (the 7x7 convolution keeps fp32 tensors).
 static int bn_vec(int x_dt, int a_dt, int P) {
@@ -480,6 +489,37 @@ void mid_bn_set_sync(void *comm, int world, float *tmp, size_t tmp_floats, int f
     g_bn_sync.comm = comm; g_bn_sync.world = world; g_bn_sync.tmp = tmp; g_bn_sync.tmp_floats = tmp_floats; g_bn_sync.force = force ? 1 : 0;
 }
 size_t mid_bn_ws_floats(int C) { return (size_t)C * BN_SPLIT_MAX * 3; }
+
+/* Test aid: the device-side merge of cross-replica batch norm run on R supplied replicas of ONE process.  The launches are the
+ * ones mid_bn_fwd_t / bn_bwd_impl make around their collectives (bn_sync_k2, bn_sync_k3, bn_sync_pack, bn_sync_unpack); only the
+ * all-reduce itself is replaced by a kernel that sums the R buffers.  In / out, all [R][C] on the device:
+ *   means, vars     per-replica statistics in, the merged statistics out (every replica ends with the same row)
+ *   dgamma, dbeta   per-replica sums in (taken with the merged statistics), arena values out (sum / R: the gradient arena's own
+ *                   all-reduce SUM then restores the global value)
+ *   sums_out        [R][2C]: what the dx formula of each replica sees (sums over every replica's samples)
+ * tmp: R * 2C floats of scratch. */
+int mid_bn_debug_merge(mid_stream s, int R, int C, float *means, float *vars, float *dgamma, float *dbeta, float *sums_out, float *tmp) {
+    hipStream_t st = (hipStream_t)s;
+    if (R < 1 || C < 1) return -2;
+    const float iw = 1.0f / (float)R;
+    const size_t T = (size_t)2 * C;
+    const dim3 gc(mi_cdiv(C, 256)), g2c(mi_cdiv(2 * C, 256)), b(256);
+    if (means && vars) {
+        for (int r = 0; r < R; r++) (void)hipMemcpyAsync(tmp + r * T, means + (size_t)r * C, sizeof(float) * C, hipMemcpyDeviceToDevice, st);
+        hipLaunchKernelGGL(bn_sync_emul_allreduce, gc, b, 0, st, tmp, R, T, C);
+        for (int r = 0; r < R; r++) hipLaunchKernelGGL(bn_sync_k2, gc, b, 0, st, tmp + r * T, means + (size_t)r * C, vars + (size_t)r * C, tmp + r * T + C, C, iw);
+        hipLaunchKernelGGL(bn_sync_emul_allreduce, gc, b, 0, st, tmp + C, R, T, C);
+        for (int r = 0; r < R; r++) hipLaunchKernelGGL(bn_sync_k3, gc, b, 0, st, tmp + r * T + C, vars + (size_t)r * C, C, iw);
+    }
+    if (dgamma && dbeta) {
+        for (int r = 0; r < R; r++) hipLaunchKernelGGL(bn_sync_pack, gc, b, 0, st, dgamma + (size_t)r * C, dbeta + (size_t)r * C, tmp + r * T, C);
+        hipLaunchKernelGGL(bn_sync_emul_allreduce, g2c, b, 0, st, tmp, R, T, 2 * C);
+        if (sums_out) (void)hipMemcpyAsync(sums_out, tmp, sizeof(float) * R * T, hipMemcpyDeviceToDevice, st);
+        for (int r = 0; r < R; r++) hipLaunchKernelGGL(bn_sync_unpack, gc, b, 0, st, tmp + r * T, dgamma + (size_t)r * C, dbeta + (size_t)r * C, C, iw);
+    }
+    MI_LAUNCH_CHECK("mid_bn_debug_merge");
+    return 0;
+}
 
 /* (the bf16 kernels pad every image's columns to a multiple of 8) */
 size_t mid_bn_parts_floats(int N, int K, int Ho) { return (size_t)3 * (size_t)mi_cdiv((long)N * ((Ho * Ho + 7) / 8 * 8), 128) * 4 * K; }

@@ -1073,10 +1073,13 @@ static int bgemm_launch_t(hipStream_t st, dim3 grid, const u16 *A, const u16 *B,
         const int ksteps = (MODE == BG_FWD ? g.C : g.K) / BG_BK * KS * KS;
         lds = (ksteps == 1 || SBUF) ? tiles_b / 2 : tiles_b;
     }
+    // raised once per instantiation to the largest value any launch of it can ask for (`lds` varies at run time for the SWP forms:
+    // a one-k-step launch followed by a multi-k-step one of the same instantiation must not find the limit at the smaller value)
     static int attr_set = 0;
     if (!attr_set) {
-        if (lds > 64 * 1024 &&
-            hipFuncSetAttribute((const void *)bgemm_kernel<MODE, KS, S, WMW, VW, SWP, SBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        constexpr size_t lds_max = tiles_b > ep_b ? tiles_b : ep_b;
+        if (lds_max > 64 * 1024 &&
+            hipFuncSetAttribute((const void *)bgemm_kernel<MODE, KS, S, WMW, VW, SWP, SBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess) {
             mi_record_error("bgemm_kernel", "cannot raise the dynamic LDS limit");
             return -1;
         }
@@ -1191,10 +1194,12 @@ int mi_bgemm_fwd(hipStream_t st, mid_workspace *ws, const u16 *x, const float *w
     BgArgs g = {};
     bgemm_geometry(g, N, C, H, K, stride);
     int svw = bgemm_stage_vw(BGOP_FWD, g.P, g.Wo, stride);
+    ws->s2d_valid = 0; // on return: 1 = this launch left x as parity planes in ws->s2d (the layer's weight gradient may reuse them)
     if (stride == 2 && svw == 8) { // the 16-byte staging reads x as parity planes: one pass over x first
         if (ws->s2d && ws->s2d_bytes >= (size_t)N * C * g.HW * 2) {
             if (bg_s2d(st, x, (u16 *)ws->s2d, (long)N * C, H, H)) return -1;
             x = (const u16 *)ws->s2d;
+            ws->s2d_valid = 1;
         } else svw = 1;
     }
     if (svw == 8) { g.Pc = (g.P + 7) / 8 * 8; g.ncols = N * g.Pc; g.fdPc = make_fastdiv(g.Pc); }

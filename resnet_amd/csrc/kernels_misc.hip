@@ -176,14 +176,27 @@ __global__ void ce_deriv_kernel(const float *__restrict__ pred, const int *__res
 // zero_grads: the gradient is cleared where it was finite (the memset of resnet.cu:2972-2978 folded in); a NaN / Inf
 // gradient STAYS in the arena, so that the diagnostic dump of check_errors (resnet.cu:2879-2907) still holds it even
 // though the flag is read only at the next host synchronisation point
+// nan_flag: 0 = clean, else (highest offending locations[] index + 1) -- the reference's check_errors walks locations[] from
+// the last to the first and names the first it finds (resnet.cu:2879-2907, :2952).  loc_off (optional): the n_loc + 1 float
+// offsets of the tensors in the arena; `base` = arena offset of p[0] (a bucket launch starts mid-arena).  Without a table the
+// flag is 1.  The search runs only for an offending element.
+__device__ __forceinline__ int adam_loc_of(const size_t *__restrict__ loc_off, int n_loc, size_t pos) {
+    int lo = 0, hi = n_loc - 1;
+    while (lo < hi) { // last location whose offset is <= pos
+        const int mid = (lo + hi + 1) >> 1;
+        if (loc_off[mid] <= pos) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
 __global__ void adam_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
                             size_t n, float lr, float wd, float b1, float b2, float cur_b1, float cur_b2, float eps,
-                            int *__restrict__ nan_flag, int zero_grads) {
-    bool bad = false;
+                            int *__restrict__ nan_flag, int zero_grads, const size_t *__restrict__ loc_off, int n_loc, size_t base) {
+    int bad = 0; // highest offending location + 1
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float gi = g[i], old = p[i];
         float mi = m[i], vi = v[i];
-        if (isnan(gi) || isinf(gi)) bad = true;
+        bool b = false;
+        if (isnan(gi) || isinf(gi)) b = true;
         else {
             const float gd = gi + wd * old;
             mi = b1 * mi + (1.f - b1) * gd;
@@ -193,11 +206,15 @@ __global__ void adam_kernel(float *__restrict__ p, float *__restrict__ g, float 
         }
         const float ma = mi / (1.f - cur_b1), va = vi / (1.f - cur_b2);
         float np = old - (lr * (ma / (sqrtf(va) + eps)) + wd * old);
-        if (isnan(np) || isinf(np)) { np = old; bad = true; }
-        if (isnan(mi) || isinf(mi) || isnan(vi) || isinf(vi)) bad = true;
+        if (isnan(np) || isinf(np)) { np = old; b = true; }
+        if (isnan(mi) || isinf(mi) || isnan(vi) || isinf(vi)) b = true;
         p[i] = np;
+        if (b) {
+            const int l = loc_off ? adam_loc_of(loc_off, n_loc, base + i) + 1 : 1;
+            bad = l > bad ? l : bad;
+        }
     }
-    if (bad && nan_flag) atomicOr(nan_flag, 1);
+    if (bad && nan_flag) atomicMax(nan_flag, bad);
 }
 
 // ---- layout ----
@@ -332,8 +349,9 @@ int mid_ce_deriv(mid_stream s, const float *pred, const int *labels, float *d, i
     return 0;
 }
 int mid_adam(mid_stream s, float *p, float *g, float *m, float *v, size_t n, float lr, float wd, float b1, float b2,
-             float cur_b1, float cur_b2, float eps, int *nan_flag, int zero_grads) {
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)s, p, g, m, v, n, lr, wd, b1, b2, cur_b1, cur_b2, eps, nan_flag, zero_grads);
+             float cur_b1, float cur_b2, float eps, int *nan_flag, int zero_grads, const size_t *loc_off_dev, int n_loc, size_t base) {
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)s, p, g, m, v, n, lr, wd, b1, b2, cur_b1, cur_b2, eps, nan_flag, zero_grads,
+                       loc_off_dev, n_loc, base);
     MI_LAUNCH_CHECK("adam_kernel");
     return 0;
 }

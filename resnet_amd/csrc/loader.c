@@ -33,6 +33,7 @@ void mi_batch_ext_free(Batch *b) {
         mid_free(e->images_next); mid_free(e->stage_next); mid_free(e->labels_next);
         mid_free_host(e->pinned_next); mid_free_host(e->labels_next_host);
         if (e->ev_next) mid_event_destroy(e->ev_next);
+        if (e->ev_compute) mid_event_destroy(e->ev_compute);
         free(e);
     }
     mid_free_host(b->images_float_cpu); mid_free_host(b->correct_classes_cpu);
@@ -73,6 +74,7 @@ void mi_batch_set_prefetch(Batch *b, int on) {
         e->labels_next = (int *)mid_malloc((size_t)b->n_images * sizeof(int));
         e->labels_next_host = (int *)mid_malloc_host((size_t)b->n_images * sizeof(int));
         e->ev_next = mid_event_create();
+        e->ev_compute = mid_event_create();
     }
 }
 /* enqueue batch (shard resident in host RAM, index bi) on the copy stream into the *_next buffers */
@@ -82,6 +84,12 @@ static void prefetch_enqueue(Batch *b, BatchExt *e, int bi) {
     const size_t px = (size_t)N * b->image_size, bytes = px * sizeof(float);
     memcpy(e->pinned_next, b->full_shard_images + (size_t)bi * px, bytes);
     memcpy(e->labels_next_host, b->full_shard_correct_classes + (size_t)bi * N, (size_t)N * sizeof(int));
+    /* images_next / labels_next were the PREVIOUS step's batch until the swap a moment ago: that step's backward (stem weight
+     * gradient) and update_parameters' input_reset memsets may still be queued on the compute stream against them, and
+     * update_parameters no longer synchronises the host.  The copy stream therefore waits for everything the compute stream
+     * holds right now before it overwrites the buffers (an event, not a host sync: the caller goes on queueing). */
+    mid_event_record(e->ev_compute, g->compute);
+    mid_stream_wait_event(g->copy, e->ev_compute);
     if (e->layout == MI_LAYOUT_NHWC) {
         mid_memcpy_h2d(e->stage_next, e->pinned_next, bytes, g->copy);
         mid_nhwc_to_nchw(g->copy, e->stage_next, e->images_next, N, b->image_dim, b->image_dim, b->image_size / (b->image_dim * b->image_dim));
@@ -155,6 +163,7 @@ static void upload(Batch *b, BatchExt *e) {
 /* resnet.cu:1235-1325 */
 void load_new_batch(Train_ResNet *trainer, Class_Metadata *class_metadata, Batch *b) {
     (void)class_metadata;
+    mi_trainer_poll_errors(trainer); /* check_errors of the step that just ended, while its batch and activations are still there */
     BatchExt *e = mi_batch_ext(b);
     MiGlobal *g = mi_global();
     const int N = b->n_images;
@@ -197,8 +206,8 @@ void load_new_batch(Train_ResNet *trainer, Class_Metadata *class_metadata, Batch
                 upload(b, e);
             }
             if (e->prefetch && (b->cur_batch_in_shard + 2) * W * N <= b->shard_n_images) {
-                /* the swapped-out buffer may still be read by the step that just ended: that step was synchronised by
-                 * update_parameters / forward_pass before the caller got here, so the copy stream can reuse it */
+                /* the swapped-out buffer may still be read (stem weight gradient) and cleared (input_reset) by the step that
+                 * just ended: prefetch_enqueue orders the copy stream behind the compute stream before writing into it */
                 prefetch_enqueue(b, e, (b->cur_batch_in_shard + 1) * W + R);
             }
         }

@@ -192,6 +192,8 @@ int mid_bn_fwd_t(mid_stream s, float *stats_ws, const mid_bn_parts *parts, const
                  float *norm_out, int N, int C, int P, float eps, int relu);
 /* cross-replica batch-norm statistics through `comm` (an RCCL communicator of its own); NULL = per-replica (the reference) */
 void mid_bn_set_sync(void *comm, int world, float *tmp, size_t tmp_floats, int force);
+/* test aid: the sync-BN merge kernels on R replicas held by one process (the all-reduce replaced by a sum kernel); see kernels_bn.hip */
+int mid_bn_debug_merge(mid_stream s, int R, int C, float *means, float *vars, float *dgamma, float *dbeta, float *sums_out, float *tmp);
 int mid_bn_stats_t(mid_stream s, float *stats_ws, const void *x, int x_dt, float *means, float *vars, int N, int C, int P);
 int mid_bn_apply_t(mid_stream s, const void *x, int x_dt, const float *gamma, const float *beta, const void *residual,
                    const float *means, const float *vars, void *y, int a_dt, int N, int C, int P, float eps, int relu);
@@ -214,9 +216,12 @@ int mid_relu_deriv(mid_stream s, const float *x, const float *up, float *out, si
 int mid_add_relu(mid_stream s, const float *a, const float *b, float *sum_out, float *act_out, size_t n);
 int mid_softmax(mid_stream s, const float *x, float *out, int N, int L);
 int mid_ce_deriv(mid_stream s, const float *pred, const int *labels, float *d, int N, int L);
-/* fused updateMeans+updateVars+updateParams (resnet.cu:605-662); sets *nan_flag (device int) on NaN/Inf */
+/* fused updateMeans+updateVars+updateParams (resnet.cu:605-662).  On NaN/Inf *nan_flag (device int) becomes the highest offending
+ * locations[] index + 1 (check_errors, resnet.cu:2879-2907): loc_off_dev = n_loc + 1 arena offsets (floats) of the tensors, base =
+ * arena offset of p[0]; loc_off_dev NULL: the flag becomes 1. */
 int mid_adam(mid_stream s, float *p, float *g, float *m, float *v, size_t n, float lr, float wd, float b1,
-             float b2, float cur_b1, float cur_b2, float eps, int *nan_flag, int zero_grads);
+             float b2, float cur_b1, float cur_b2, float eps, int *nan_flag, int zero_grads, const size_t *loc_off_dev, int n_loc,
+             size_t base);
 int mid_nhwc_to_nchw(mid_stream s, const float *in, float *out, int N, int H, int W, int C);
 int mid_nchw_to_nhwc(mid_stream s, const float *in, float *out, int N, int C, int H, int W);
 /* splitmix64 counter streams on device (synthetic batches): uniform in [lo,hi) / labels mod n_classes */

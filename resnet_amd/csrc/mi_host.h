@@ -36,14 +36,15 @@ typedef struct BatchExt {
     int prefetch, have_next, next_shard_id, next_batch_in_shard;
     float *images_next, *stage_next, *pinned_next;
     int *labels_next, *labels_next_host;
-    mid_event ev_next;
+    mid_event ev_next, ev_compute; /* copy done / compute stream's position when the target buffers were handed to the copy stream */
     uint64_t synth_step;
     struct BatchExt *next;
 } BatchExt;
 BatchExt *mi_batch_ext(Batch *b);
 void mi_batch_ext_free(Batch *b);
 
-typedef struct { void *spatial, *proj; size_t spatial_bytes, proj_bytes; } MiParity; /* parity copies of a striding block's conv inputs */
+/* parity copies of a striding block's conv inputs; *_valid: the last forward pass wrote the planes (the weight gradient may read them) */
+typedef struct { void *spatial, *proj; size_t spatial_bytes, proj_bytes; int spatial_valid, proj_valid; } MiParity;
 typedef struct MiCtx {
     mid_workspace ws;
     float *bn_ws;
@@ -57,6 +58,10 @@ typedef struct MiCtx {
     int fuse_bn_stats;
     int *nan_flag_dev, *nan_flag_host;
     int nan_check_pending;       /* update_parameters queued a copy of the flag; read it at the next host sync point */
+    mid_event ev_nan;            /* recorded behind that copy */
+    size_t *loc_off_dev; int n_loc; /* arena offsets of locations[] (+ the arena's end) for the Adam kernel's report */
+    int nan_location, nan_no_exit;  /* last reported locations[] index (-1 none); test hook: report without exit(1) */
+    struct MiCtx *next_live;     /* registry of live contexts (communicator teardown on a fatal error) */
     int full_store, dump_every, input_reset;
     int dtype;                   /* MID_F32 | MID_BF16: storage type of activations and activation gradients */
     int policy;                  /* MI_STORE_FAST | MI_STORE_RECOMPUTE_BN | MI_STORE_FULL */
@@ -74,7 +79,9 @@ typedef struct MiCtx {
     int counting_act;
     int overlap_set;             /* mi_trainer_set_overlap was called: keep the caller's mode */
     MiParity *par;               /* bf16: per block, NULL buffers for blocks that do not stride */
-    int params_dirty;            /* parameters written from the host since the last weight re-layout */
+    int params_dirty;            /* update_parameters ran since the last weight re-layout */
+    unsigned long host_epoch_seen; /* the process-wide host-write count (mi_copy_to_device) that re-layout was made at */
+    void *cur_par; size_t cur_par_bytes; int *cur_par_valid; /* parity buffer of the stride-2 convolution about to be launched */
     char *dump_root;
     /* every device allocation of this trainer (freed by destroy_trainer) */
     void **allocs;
@@ -122,5 +129,6 @@ int mi_dp_plan_buckets(const Dims *d, size_t bucket_bytes, size_t *from, size_t 
 size_t mi_params_arena_floats(const Params *p);
 float *mi_params_arena_base(const Params *p);
 void mi_dp_reduce_ready(Train_ResNet *t, size_t from_float_offset, int force);
+void mi_trainer_poll_errors(Train_ResNet *t); /* load_new_batch: wait for and read the NaN / Inf flag of the last update */
 
 #endif

@@ -98,7 +98,7 @@ int mi_op_softmax(const float *x, float *out, int N, int L) { return finish(mid_
 int mi_op_ce_deriv(const float *pred, const int *labels, float *d, int N, int L) { return finish(mid_ce_deriv(mi_global()->compute, pred, labels, d, N, L)); }
 int mi_op_adam(float *p, const float *g, float *m, float *v, size_t n, float lr, float wd, float b1, float b2, float cur_b1,
                float cur_b2, float eps, int *nan_flag_dev) {
-    return finish(mid_adam(mi_global()->compute, p, (float *)g, m, v, n, lr, wd, b1, b2, cur_b1, cur_b2, eps, nan_flag_dev, 0));
+    return finish(mid_adam(mi_global()->compute, p, (float *)g, m, v, n, lr, wd, b1, b2, cur_b1, cur_b2, eps, nan_flag_dev, 0, NULL, 0, 0));
 }
 int mi_op_nhwc_to_nchw(const float *in, float *out, int N, int H, int W, int C) { return finish(mid_nhwc_to_nchw(mi_global()->compute, in, out, N, H, W, C)); }
 int mi_op_fill_uniform(float *out, size_t n, uint64_t seed, float lo, float hi) { return finish(mid_fill_uniform(mi_global()->compute, out, n, seed, 0, lo, hi)); }
@@ -274,3 +274,14 @@ int mi_op_avgpool_fwd_t(const void *x, int dt, float *y, int N, int C, int H) { 
 int mi_op_avgpool_bwd_t(const float *dy, void *dx, int dt, int N, int C, int H) { return finish(mid_avgpool_bwd_t(mi_global()->compute, dy, dx, dt, N, C, H * H)); }
 int mi_bf16_conv_supported(int op, int N, int C, int H, int K, int k, int stride) { return mid_bf16_supported(op, N, C, H, K, k, stride); }
 void mi_clear_error(void) { mid_clear_error(); }
+
+/* the device-side merge of cross-replica batch norm on R replicas held by one process (see mid_bn_debug_merge): lets a one-GPU
+ * box check the merge against whole-batch statistics with two DIFFERENT replicas.  All pointers device, [R][C]; sums_out [R][2C]
+ * or NULL; (means, vars) or (dgamma, dbeta) may be NULL to run one half only. */
+int mi_debug_bn_merge(int R, int C, float *means, float *vars, float *dgamma, float *dbeta, float *sums_out) {
+    float *tmp = (float *)mid_malloc((size_t)R * 2 * C * sizeof(float));
+    if (!tmp) return -3;
+    int rc = finish(mid_bn_debug_merge(mi_global()->compute, R, C, means, vars, dgamma, dbeta, sums_out, tmp));
+    mid_free(tmp);
+    return rc;
+}

@@ -37,9 +37,13 @@ int mi_device_count(void) { return mid_device_count(); }
 int mi_set_device(int device) { return mid_set_device(device); }
 const char *mi_last_error(void) { return mid_last_error(); }
 void mi_device_synchronize(void) { mid_device_sync(); }
-static int g_params_dirty = 0; /* any host write into device memory may have been a parameter (weight injection, resume) */
-void mi_params_mark_dirty(void) { g_params_dirty = 1; }
-void mi_copy_to_device(void *d, const void *s, size_t n) { MiGlobal *g = mi_global(); mid_memcpy_h2d(d, s, n, g->compute); mid_stream_sync(g->compute); g_params_dirty = 1; }
+/* Any host write into device memory may have been a parameter (weight injection, resume).  mi_copy_to_device knows no trainer,
+ * so it advances a process-wide write counter; every trainer remembers the count its re-laid weight copies were made at
+ * (MiCtx.host_epoch_seen) and its own "Adam ran since" flag (MiCtx.params_dirty): staleness is per trainer, two trainers in one
+ * process cannot clear each other's. */
+static unsigned long g_host_write_epoch = 0;
+void mi_params_mark_dirty(void) { g_host_write_epoch++; }
+void mi_copy_to_device(void *d, const void *s, size_t n) { MiGlobal *g = mi_global(); mid_memcpy_h2d(d, s, n, g->compute); mid_stream_sync(g->compute); g_host_write_epoch++; }
 void mi_copy_to_host(void *d, const void *s, size_t n) { MiGlobal *g = mi_global(); mid_memcpy_d2h(d, s, n, g->compute); mid_stream_sync(g->compute); }
 
 void mi_prof_enable(int on) { mid_prof_enable(on); }
@@ -74,10 +78,19 @@ static void ctx_free_from(MiCtx *c, int first) {
     for (int i = first; i < c->n_allocs; i++) { mid_free(c->allocs[i]); c->dev_bytes -= c->alloc_bytes[i]; }
     c->n_allocs = first;
 }
+/* every live trainer context: a rank that is about to exit on an error tears ALL its communicators down first (gradient
+ * buckets and sync-BN), so that its peers' collectives fail instead of hanging */
+static MiCtx *g_live = NULL;
+static void abort_all_comms(void) {
+    for (MiCtx *c = g_live; c; c = c->next_live) {
+        if (c->comm) { mid_rccl_comm_abort(c->comm); c->comm = NULL; }
+        if (c->sync_bn_comm) { mid_bn_set_sync(NULL, 1, NULL, 0, 0); mid_rccl_comm_abort(c->sync_bn_comm); c->sync_bn_comm = NULL; }
+    }
+}
 /* a launcher that fails leaves unwritten tensors behind: stop like the allocation failure does (the reference's void
  * API gives its caller nothing to poll) */
 static void ck(int rc, const char *what) {
-    if (rc) { fprintf(stderr, "resnet_mi: %s failed (%d): %s\n", what, rc, mid_last_error()); exit(1); }
+    if (rc) { fprintf(stderr, "resnet_mi: %s failed (%d): %s\n", what, rc, mid_last_error()); abort_all_comms(); exit(1); }
 }
 
 /* resnet.cu:666-682 */
@@ -514,6 +527,20 @@ Train_ResNet *init_trainer(ResNet *model, Batch *cur_batch, int batch_size, floa
     c->g_arena = mi_params_arena_base(bb->param_derivs);
     c->m_arena = mi_params_arena_base(bb->prev_means);
     c->v_arena = mi_params_arena_base(bb->prev_vars);
+    { /* arena offsets of the tensors, for the Adam kernel's "which location" report */
+        const Params *mp = model->params;
+        size_t *lo = (size_t *)malloc(sizeof(size_t) * (size_t)(mp->n_locations + 1));
+        for (int i = 0; i < mp->n_locations; i++) lo[i] = (size_t)(mp->locations[i] - mp->locations[0]);
+        lo[mp->n_locations] = c->arena_floats;
+        c->loc_off_dev = (size_t *)mi_ctx_alloc(c, sizeof(size_t) * (size_t)(mp->n_locations + 1));
+        mid_memcpy_h2d(c->loc_off_dev, lo, sizeof(size_t) * (size_t)(mp->n_locations + 1), G.compute);
+        mid_stream_sync(G.compute);
+        free(lo);
+        c->n_loc = mp->n_locations;
+    }
+    c->ev_nan = mid_event_create();
+    c->nan_location = -1;
+    c->next_live = g_live; g_live = c;
     c->nan_flag_dev = (int *)mi_ctx_alloc(c, sizeof(int));
     c->nan_flag_host = (int *)mid_malloc_host(sizeof(int));
     *c->nan_flag_host = 0;
@@ -668,8 +695,10 @@ static const mid_wt_entry *wt_lookup(const MiCtx *c, const float *w) {
 static void relayout_weights(MiCtx *c) {
     if (c->dtype == MID_BF16) ck(mid_conv_prelayout_all_bf16(G.compute, c->wt_tab_dev, c->wt_tile_entry_dev, c->wt_tiles), "weight re-layout (bf16)");
     else ck(mid_conv_prelayout_all(G.compute, c->wt_tab_dev, c->wt_tile_entry_dev, c->wt_tiles), "weight re-layout");
-    g_params_dirty = 0;
+    c->params_dirty = 0;
+    c->host_epoch_seen = g_host_write_epoch;
 }
+static int weights_stale(const MiCtx *c) { return c->params_dirty || c->host_epoch_seen != g_host_write_epoch; }
 /* the NaN / Inf flag update_parameters queued a copy of; valid after any later synchronisation of the compute stream
  * (check_errors, resnet.cu:2879-2907: dump id 99999999 and exit; offending gradients are still in the arena, the Adam
  * kernel clears only finite ones) */
@@ -679,22 +708,43 @@ static void poll_nan_flag(Train_ResNet *t) {
     if (!c->nan_check_pending) return;
     c->nan_check_pending = 0;
     if (*c->nan_flag_host) {
-        printf("ERROR: nan or inf found in parameters, gradients or Adam moments\n");
+        /* the Adam kernel left (highest offending locations[] index + 1): the tensor check_errors would have named first,
+         * walking locations[] from the last to the first (resnet.cu:2896, :2952) */
+        printf("ERROR: nan or inf found at location: %d\n", *c->nan_flag_host - 1);
         printf("Dumping data to id=99999999 and exiting...\n");
+        c->nan_location = *c->nan_flag_host - 1;
+        if (c->dp_pending) mid_stream_sync(G.comm);
         dump_trainer(99999999, t, t->dump_dir);
-        if (c->comm) mid_rccl_comm_abort(c->comm); /* do not leave the peers waiting in a collective */
+        if (c->nan_no_exit) { /* test hook: report through mi_trainer_check_errors instead of exiting; the run goes on from a clean flag */
+            mid_memset(c->nan_flag_dev, 0, sizeof(int), G.compute);
+            mid_stream_sync(G.compute);
+            *c->nan_flag_host = 0;
+            return;
+        }
+        abort_all_comms(); /* do not leave the peers waiting in a collective */
         exit(1);
     }
+}
+/* load_new_batch calls this before it replaces the batch: the flag copy update_parameters queued is waited for (one event, the
+ * step is over by then), so that a 99999999 dump holds the OFFENDING step's inputs, activations and dump id -- what
+ * resnet.cu:2879-2907 dumps from inside update_parameters */
+void mi_trainer_poll_errors(Train_ResNet *t) {
+    MiCtx *c = ctx_of(t);
+    if (!c || !c->nan_check_pending) return;
+    mid_event_sync(c->ev_nan);
+    poll_nan_flag(t);
 }
 
 /* conv + BN (+ReLU | +residual+ReLU): prepareAndDoConvolution + prepareAndDoBatchNormAndActivate.
  * stem: the 7x7 convolution keeps fp32 input / output in every storage type; only its BN output is an activation tensor */
-static void *g_par; static size_t g_par_bytes; /* parity copy of the NEXT stride-2 convolution's input (set by the caller) */
+/* c->cur_par: parity copy of the NEXT stride-2 convolution's input (set by the caller); c->cur_par_valid: where the forward pass
+ * records whether it really wrote the planes (it does only on the 16-byte staging route), read back by the weight gradient */
+static void set_cur_par(MiCtx *c, void *buf, size_t bytes, int *valid) { c->cur_par = buf; c->cur_par_bytes = bytes; c->cur_par_valid = valid; }
 static void unit_fwd(Train_ResNet *t, const float *in, const float *w, const BatchNorm *bn, Cache_BatchNorm *cache,
                      float *conv_out, float *act_out, const float *residual, int C, int H, int K, int k, int stride,
                      int relu, int stem) {
     MiCtx *c = ctx_of(t);
-    c->ws.s2d = stride == 2 ? g_par : NULL; c->ws.s2d_bytes = stride == 2 ? g_par_bytes : 0; c->ws.s2d_valid = 0;
+    c->ws.s2d = stride == 2 ? c->cur_par : NULL; c->ws.s2d_bytes = stride == 2 ? c->cur_par_bytes : 0; c->ws.s2d_valid = 0;
     const int N = t->batch_size, Ho = H / stride;
     const int bf = c->dtype == MID_BF16 && !stem;
     /* the convolution leaves per-tile (count, mean, M2) partials of its output: BN reads the tensor twice, not three times */
@@ -708,13 +758,22 @@ static void unit_fwd(Train_ResNet *t, const float *in, const float *w, const Bat
         parts = &c->bn_parts; /* (the stem's tensors are fp32 here, but its statistics still come from the kernel's accumulators) */
         ck(mid_stem_fwd_bf16(G.compute, in, w, conv_out, c->stem_xp, c->stem_xp_bytes, c->stem_scratch, c->stem_scratch_floats, N, H, parts),
            "stem convolution forward (bf16 operands)");
-    } else if (bf) ck(mid_conv_fwd_bf16(G.compute, &c->ws, in, w, conv_out, N, C, H, K, k, stride, parts), "convolution forward (bf16)");
-    else ck(mid_conv_fwd_stats(G.compute, &c->ws, in, w, conv_out, N, C, H, K, k, stride, parts), "convolution forward");
+    } else if (bf) {
+        ck(mid_conv_fwd_bf16(G.compute, &c->ws, in, w, conv_out, N, C, H, K, k, stride, parts), "convolution forward (bf16)");
+        if (stride == 2 && c->cur_par_valid) *c->cur_par_valid = c->ws.s2d_valid; /* the launch says whether it left the parity planes */
+    } else ck(mid_conv_fwd_stats(G.compute, &c->ws, in, w, conv_out, N, C, H, K, k, stride, parts), "convolution forward");
     c->ws.pre_fwd = NULL;
     ck(mid_bn_fwd_t(G.compute, c->bn_ws, parts, conv_out, bf ? MID_BF16 : MID_F32, bn->gamma, bn->beta, residual, cache->means, cache->vars,
                     act_out, c->dtype, cache->normalized_temp, cache->normalized, N, K, Ho * Ho, t->eps, relu), "batch norm forward");
 }
 
+/* the batch-norm launchers take their cross-replica setting from one process-wide slot (kernels_bn.hip): every pass binds ITS
+ * trainer's (none for a trainer without sync-BN), so two trainers in one process do not inherit each other's */
+#define MI_SYNC_BN_TMP_FLOATS (2 * 4096)
+static void bind_sync_bn(const MiCtx *c) {
+    if (c->sync_bn && c->sync_bn_comm) mid_bn_set_sync(c->sync_bn_comm, c->world, c->sync_bn_tmp, MI_SYNC_BN_TMP_FLOATS, 1);
+    else mid_bn_set_sync(NULL, 1, NULL, 0, 0);
+}
 /* resnet.cu:1526-1775 */
 void forward_pass(Train_ResNet *t) {
     MiCtx *c = ctx_of(t);
@@ -723,7 +782,9 @@ void forward_pass(Train_ResNet *t) {
     Activations *a = t->forward_buffer->activations;
     const int N = t->batch_size, f = d->init_conv_filters;
     mid_event_record(c->ev_t[0], G.compute);
+    bind_sync_bn(c);
     relayout_weights(c);
+    set_cur_par(c, NULL, 0, NULL);
     unit_fwd(t, t->cur_batch->images, p->init_conv_layer, p->norm_init_conv, a->norm_init_conv, a->init_conv_applied,
              a->init_conv_activated, NULL, 3, d->input, f, d->init_kernel_dim, d->init_conv_stride, 1, 1);
     const int Hs = d->input / d->init_conv_stride;
@@ -736,12 +797,12 @@ void forward_pass(Train_ResNet *t) {
         const int H = b->incoming_spatial_dim, Ho = H / b->stride;
         unit_fwd(t, bin, b->depth_reduction, b->norm_depth_reduction, k->norm_post_reduced, k->post_reduced,
                  k->post_reduced_activated, NULL, b->incoming_filters, H, b->reduced_depth, 1, 1, 1, 0);
-        g_par = c->par ? c->par[i].spatial : NULL; g_par_bytes = c->par ? c->par[i].spatial_bytes : 0;
+        if (c->par) set_cur_par(c, c->par[i].spatial, c->par[i].spatial_bytes, &c->par[i].spatial_valid); else set_cur_par(c, NULL, 0, NULL);
         unit_fwd(t, k->post_reduced_activated, b->spatial, b->norm_spatial, k->norm_post_spatial, k->post_spatial,
                  k->post_spatial_activated, NULL, b->reduced_depth, H, b->reduced_depth, 3, b->stride, 1, 0);
         const float *res = bin;
         if (b->projection) { /* resnet.cu:1685-1704 */
-            g_par = c->par ? c->par[i].proj : NULL; g_par_bytes = c->par ? c->par[i].proj_bytes : 0;
+            if (c->par) set_cur_par(c, c->par[i].proj, c->par[i].proj_bytes, &c->par[i].proj_valid); else set_cur_par(c, NULL, 0, NULL);
             unit_fwd(t, bin, b->projection, b->norm_projection, k->norm_post_projection, k->transformed_residual,
                      k->post_projection_norm_vals, NULL, b->incoming_filters, H, b->expanded_depth, b->stride == 2 ? 3 : 1,
                      b->stride, 0, 0);
@@ -818,7 +879,8 @@ static void conv_wgrad_t(Train_ResNet *t, mid_stream st, const float *x, const f
                          int stem) {
     MiCtx *c = ctx_of(t);
     /* the forward pass left the parity planes of x in the layer's own buffer: the weight gradient reads them again */
-    c->ws.s2d = stride == 2 ? g_par : NULL; c->ws.s2d_bytes = stride == 2 ? g_par_bytes : 0; c->ws.s2d_valid = stride == 2 && g_par != NULL;
+    c->ws.s2d = stride == 2 ? c->cur_par : NULL; c->ws.s2d_bytes = stride == 2 ? c->cur_par_bytes : 0;
+    c->ws.s2d_valid = stride == 2 && c->cur_par != NULL && c->cur_par_valid && *c->cur_par_valid;
     if (stem && c->stem_scratch && c->dtype == MID_F32)
         ck(mid_stem_wgrad_f32(st, c->stem_xp, dy, dw, c->stem_scratch, c->stem_scratch_floats, t->batch_size, H), "stem convolution wgrad (fp32 matrix cores)");
     else if (stem && c->stem_scratch) /* the forward pass left the batch as padded bf16 parity planes */
@@ -878,7 +940,8 @@ void backwards_pass(Train_ResNet *t) {
     const int N = t->batch_size, L = d->output, D = d->final_depth, nb = d->n_conv_blocks;
     const int recompute = c->policy == MI_STORE_RECOMPUTE_BN;
     mid_event_record(c->ev_t[2], G.compute);
-    if (g_params_dirty) relayout_weights(c); /* parameters were rewritten from the host after forward_pass */
+    bind_sync_bn(c);
+    if (weights_stale(c)) relayout_weights(c); /* parameters were rewritten from the host after forward_pass */
     c->dp_cursor = c->arena_floats;
     c->n_buckets = 0;
     /* dlogits = softmax - onehot, batch SUM (no 1/N: resnet.cu:1806-1811) */
@@ -915,7 +978,7 @@ void backwards_pass(Train_ResNet *t) {
         if (b->projection) {
             /* ReLU' of the block output (doActivationDeriv, :1934) is fused into the projection BN' as an external mask; that
              * pass also leaves relu'(out) * up in dk->output, which the expansion BN' then reads instead of up + mask */
-            g_par = c->par ? c->par[i].proj : NULL; g_par_bytes = c->par ? c->par[i].proj_bytes : 0;
+            if (c->par) set_cur_par(c, c->par[i].proj, c->par[i].proj_bytes, &c->par[i].proj_valid); else set_cur_par(c, NULL, 0, NULL);
             unit_bwd(t, bin, b->projection, b->norm_projection, k->norm_post_projection, db->norm_projection,
                      k->transformed_residual, up, k->output_activated, 3, dk->output, dk->transformed_residual, s_proj, dbin, NULL,
                      db->projection, b->incoming_filters, H, b->expanded_depth, b->stride == 2 ? 3 : 1, b->stride, 0);
@@ -941,7 +1004,7 @@ void backwards_pass(Train_ResNet *t) {
             ck(mid_bn_apply_t(G.compute, k->post_reduced, c->dtype, b->norm_depth_reduction->gamma, b->norm_depth_reduction->beta, NULL,
                               k->norm_post_reduced->means, k->norm_post_reduced->vars, k->post_reduced_activated, c->dtype, N, b->reduced_depth,
                               H * H, t->eps, 1), "BN recompute");
-        g_par = c->par ? c->par[i].spatial : NULL; g_par_bytes = c->par ? c->par[i].spatial_bytes : 0;
+        if (c->par) set_cur_par(c, c->par[i].spatial, c->par[i].spatial_bytes, &c->par[i].spatial_valid); else set_cur_par(c, NULL, 0, NULL);
         FZ_REQ(k->post_reduced, k->post_reduced_activated, k->norm_post_reduced->means); /* spatial dgrad -> reduction BN' */
         unit_bwd(t, k->post_reduced_activated, b->spatial, b->norm_spatial, k->norm_post_spatial, db->norm_spatial,
                  k->post_spatial, dk->post_spatial_activated, NULL, 1, NULL, dk->post_spatial, s_spa, dk->post_reduced_activated, NULL,
@@ -963,6 +1026,7 @@ void backwards_pass(Train_ResNet *t) {
     if (ring) { da->init_conv_activated = ring_take(c, NULL); da->init_conv_applied = ring_take(c, &s_stem); }
     ck(mid_maxpool_bwd_t(G.compute, a->max_inds, da->init_convblock_input, da->init_conv_activated, c->dtype, N, d->init_conv_filters, Hs,
                          d->init_maxpool_dim, d->init_maxpool_stride), "max-pool backward");
+    set_cur_par(c, NULL, 0, NULL); /* the stem strides too, but has its own padded planes (stem_xp) */
     unit_bwd(t, t->cur_batch->images, p->init_conv_layer, p->norm_init_conv, a->norm_init_conv, dp->norm_init_conv,
              a->init_conv_applied, da->init_conv_activated, NULL, 1, NULL, da->init_conv_applied, s_stem, NULL, NULL,
              dp->init_conv_layer, 3, d->input, d->init_conv_filters, d->init_kernel_dim, d->init_conv_stride, 1);
@@ -991,9 +1055,11 @@ int mi_dp_plan_buckets(const Dims *d, size_t bucket_bytes, size_t *from, size_t 
     const size_t fc_off = off;
     int n = 0;
     size_t cursor = arena;
+    /* at most MI_MAX_BUCKETS buckets (one event each): the last slot is kept for the forced final cut, so a network with more
+     * cut points than slots gets a larger last bucket, never a lost range */
 #define CUT(from_, force_)                                                                      \
     do {                                                                                        \
-        if ((from_) < cursor && ((force_) || (cursor - (from_)) * sizeof(float) >= bucket_bytes)) { \
+        if ((from_) < cursor && ((force_) || ((cursor - (from_)) * sizeof(float) >= bucket_bytes && n < MI_MAX_BUCKETS - 1))) { \
             if (n < max) { from[n] = (from_); to[n] = cursor; }                                  \
             n++; cursor = (from_);                                                              \
         }                                                                                       \
@@ -1017,14 +1083,14 @@ void mi_dp_reduce_ready(Train_ResNet *t, size_t from, int force) {
     if (from >= c->dp_cursor) return;
     const size_t n = c->dp_cursor - from;
     if (!force && n * sizeof(float) < c->bucket_bytes) return;
-    if (c->n_buckets >= MI_MAX_BUCKETS) { if (!force) return; from = 0; } /* more cuts than event slots: the rest goes as one */
+    if (!force && c->n_buckets >= MI_MAX_BUCKETS - 1) return; /* the last event slot is kept for the forced final cut (mi_dp_plan_buckets) */
     mid_event_record(c->ev_grads, G.compute);
     mid_stream_wait_event(G.comm, c->ev_grads);
     /* the bucket also holds weight gradients from the aux stream: the comm stream waits for the latest of them itself,
      * the compute stream does not stall */
     if (pending) mid_stream_wait_event(G.comm, c->ev_wgrad_done);
     ck(mid_rccl_allreduce_sum(c->comm, c->g_arena + from, c->dp_cursor - from, G.comm), "RCCL all-reduce");
-    const int b = c->n_buckets < MI_MAX_BUCKETS ? c->n_buckets++ : MI_MAX_BUCKETS - 1;
+    const int b = c->n_buckets++; /* < MI_MAX_BUCKETS by the rule above */
     c->bk_from[b] = from; c->bk_to[b] = c->dp_cursor;
     mid_event_record(c->bk_ev[b], G.comm);
     c->dp_cursor = from;
@@ -1051,13 +1117,13 @@ void update_parameters(Train_ResNet *t) {
             mid_stream_wait_event(G.compute, c->bk_ev[b]);
             const size_t o = c->bk_from[b], n = c->bk_to[b] - c->bk_from[b];
             ck(mid_adam(G.compute, p_arena + o, c->g_arena + o, c->m_arena + o, c->v_arena + o, n, t->learning_rate, t->weight_decay,
-                        t->base_mean_decay, t->base_var_decay, cur_b1, cur_b2, t->eps, c->nan_flag_dev, 1), "Adam");
+                        t->base_mean_decay, t->base_var_decay, cur_b1, cur_b2, t->eps, c->nan_flag_dev, 1, c->loc_off_dev, c->n_loc, o), "Adam");
         }
         c->dp_pending = 0; c->n_buckets = 0;
     } else {
         /* one launch over the whole arena; it also clears the gradients (:2972-2978) */
         ck(mid_adam(G.compute, p_arena, c->g_arena, c->m_arena, c->v_arena, c->arena_floats, t->learning_rate, t->weight_decay,
-                    t->base_mean_decay, t->base_var_decay, cur_b1, cur_b2, t->eps, c->nan_flag_dev, 1), "Adam");
+                    t->base_mean_decay, t->base_var_decay, cur_b1, cur_b2, t->eps, c->nan_flag_dev, 1, c->loc_off_dev, c->n_loc, 0), "Adam");
     }
     if (c->input_reset) { /* :2981-2982 */
         mid_memset(t->cur_batch->images, 0, (size_t)t->batch_size * t->cur_batch->image_size * sizeof(float), G.compute);
@@ -1065,8 +1131,9 @@ void update_parameters(Train_ResNet *t) {
     }
     mid_event_record(c->ev_t[5], G.compute);
     mid_memcpy_d2h(c->nan_flag_host, c->nan_flag_dev, sizeof(int), G.compute);
+    mid_event_record(c->ev_nan, G.compute);
     c->nan_check_pending = 1;
-    g_params_dirty = 1; /* the re-laid weight copies are stale until the next forward_pass */
+    c->params_dirty = 1; /* the re-laid weight copies are stale until the next forward_pass */
     t->cur_mean_decay = cur_b1;
     t->cur_var_decay = cur_b2;
 }
@@ -1089,6 +1156,18 @@ int mi_trainer_check_errors(Train_ResNet *t) {
     poll_nan_flag(t);
     return bad;
 }
+/* the locations[] index the last NaN / Inf report named (-1: none); mi_trainer_set_nan_exit(t, 0) makes the report return through
+ * mi_trainer_check_errors instead of exit(1) (tests) */
+int mi_trainer_nan_location(const Train_ResNet *t) { return ((const MiCtx *)t->backend_ctx)->nan_location; }
+void mi_trainer_set_nan_exit(Train_ResNet *t, int on) {
+    MiCtx *c = ctx_of(t);
+    c->nan_no_exit = !on;
+    if (on) return;
+    /* a run that goes on after a report starts from a clean flag */
+    mid_memset(c->nan_flag_dev, 0, sizeof(int), G.compute);
+    mid_stream_sync(G.compute);
+    *c->nan_flag_host = 0;
+}
 
 /* ---------------------------------------------------------------------------------------------- */
 static void free_activations_host(Activations *a) {
@@ -1107,6 +1186,8 @@ void destroy_trainer(Train_ResNet *t) {
     MiCtx *c = ctx_of(t);
     mid_device_sync();
     const Dims *d = t->model->dims;
+    for (MiCtx **pp = &g_live; *pp; pp = &(*pp)->next_live) if (*pp == c) { *pp = c->next_live; break; }
+    mid_event_destroy(c->ev_nan);
     if (c->comm) mid_rccl_comm_destroy(c->comm);
     if (c->sync_bn_comm) { mid_bn_set_sync(NULL, 1, NULL, 0, 0); mid_rccl_comm_destroy(c->sync_bn_comm); mid_free(c->sync_bn_tmp); }
     for (int i = 0; i < c->n_allocs; i++) mid_free(c->allocs[i]);
@@ -1154,11 +1235,11 @@ void mi_dp_set_bucket_bytes(Train_ResNet *t, size_t bytes) { ctx_of(t)->bucket_b
  * broadcast like the first.  With it, DP-N equals one replica at batch N x 256 up to summation order. */
 int mi_dp_enable_sync_bn(Train_ResNet *t, const void *unique_id, int bytes) {
     MiCtx *c = ctx_of(t);
-    if (!unique_id) { mid_bn_set_sync(NULL, 1, NULL, 0, 0); return 0; }
-    if (c->sync_bn_comm) return 0;
+    if (!unique_id) { c->sync_bn = 0; mid_bn_set_sync(NULL, 1, NULL, 0, 0); return 0; }
+    if (c->sync_bn_comm) { c->sync_bn = 1; return 0; }
     c->sync_bn_comm = mid_rccl_comm_init(c->rank, c->world, unique_id, bytes);
     if (!c->sync_bn_comm) return -1;
-    const size_t nf = 2 * 4096;
+    const size_t nf = MI_SYNC_BN_TMP_FLOATS;
     c->sync_bn_tmp = (float *)mid_malloc(nf * sizeof(float));
     mid_bn_set_sync(c->sync_bn_comm, c->world, c->sync_bn_tmp, nf, 1);
     c->sync_bn = 1;

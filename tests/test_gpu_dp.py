@@ -231,3 +231,59 @@ def test_sync_bn_option_one_rank_is_the_identity():
     assert np.array_equal(res[0][0], res[1][0])
     for a, b in zip(res[0][1] + res[0][2], res[1][1] + res[1][2]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("shape", [(6, 64, 8), (4, 256, 7), (3, 2048, 2)])
+def test_sync_bn_merge_of_two_different_replicas_equals_the_whole_batch(oracle, ops, shape):
+    """Cross-replica batch norm with two replicas that hold DIFFERENT data, on one GPU: each half of a batch of 2N images goes through
+    the product's own BN operators (per-replica statistics; backward sums taken with the merged statistics), and the merge in
+    between is mi_debug_bn_merge -- the kernels the trainer launches around its sync-BN collectives (bn_sync_k2 / k3 / pack /
+    unpack), with the all-reduce replaced by a sum over the two buffers.  Yardstick: the ORACLE's batch norm over the whole batch of
+    2N (resnet.cu:289-426): means, variances, dgamma, dbeta, and dx of both halves."""
+    from util import nhwc
+    N, Cc, H = shape
+    eps = 1e-7
+    rng = np.random.RandomState(11)
+    x = (rng.randn(2 * N, Cc, H, H) * 1.7 + rng.randn(1, Cc, 1, 1)).astype(np.float32)
+    x[N:] += 0.8  # the replicas' means differ: the (mean_r - mean_g)^2 term of the variance merge is not negligible
+    dy = rng.randn(2 * N, Cc, H, H).astype(np.float32)
+    gamma = (1 + 0.1 * rng.randn(Cc)).astype(np.float32)
+    beta = (0.1 * rng.randn(Cc)).astype(np.float32)
+    # the oracle on the whole batch (NHWC)
+    om, ov, oxhat, _onorm, oact = oracle.bn_fwd(nhwc(x), gamma, beta, eps, True)
+    odx, odg, odb = oracle.bn_bwd(nhwc(x), gamma, eps, om, ov, oxhat, oact, nhwc(dy), True)
+    # forward: per-replica statistics, then the device-side merge
+    halves = [slice(0, N), slice(N, 2 * N)]
+    stats = [ops.bn_fwd(x[h], gamma, beta, eps, True)[:2] for h in halves]
+    means = ops.dev(np.stack([s[0] for s in stats]))
+    vars_ = ops.dev(np.stack([s[1] for s in stats]))
+    assert ops.L.mi_debug_bn_merge(2, Cc, means.ptr, vars_.ptr, None, None, None) == 0, ops.L.mi_last_error()
+    gm, gv = means.get(), vars_.get()
+    assert np.array_equal(gm[0], gm[1]) and np.array_equal(gv[0], gv[1])  # every replica ends with the same statistics
+    assert rel_l2(gm[0], om) <= 1e-5 and rel_l2(gv[0], ov) <= 1e-5, (rel_l2(gm[0], om), rel_l2(gv[0], ov))
+    assert rel_l2(stats[0][0], om) > 1e-2  # (a replica's own mean is NOT the whole-batch mean here)
+    # backward: each replica's sums with the MERGED statistics and its own ReLU mask (mask_mode 1), merged, then its dx
+    per = [ops.bn_bwd(x[h], gamma, beta, gm[0], gv[0], dy[h], eps, 1) for h in halves]
+    dg = ops.dev(np.stack([p[1] for p in per]))
+    db = ops.dev(np.stack([p[2] for p in per]))
+    sums = ops.dev(shape=(2, 2 * Cc))
+    assert ops.L.mi_debug_bn_merge(2, Cc, None, None, dg.ptr, db.ptr, sums.ptr) == 0, ops.L.mi_last_error()
+    s = sums.get()
+    assert np.array_equal(s[0], s[1])
+    assert rel_l2(s[0][:Cc], odg) <= 1e-4 and rel_l2(s[0][Cc:], odb) <= 1e-4, (rel_l2(s[0][:Cc], odg), rel_l2(s[0][Cc:], odb))
+    # what goes into the gradient arena is sum / world, so that the arena's own all-reduce SUM restores the global value
+    arena_dg, arena_db = dg.get(), db.get()
+    assert rel_l2(arena_dg[0] + arena_dg[1], odg) <= 1e-4 and rel_l2(arena_db[0] + arena_db[1], odb) <= 1e-4
+    # dx of each half from the global sums: dx = gamma / sigma * (g - sum_g / M - xhat * sum_gxhat / M), M = 2 N H W
+    M = 2 * N * H * H
+    inv = gamma / np.sqrt(gv[0] + eps)
+    for r, h in enumerate(halves):
+        xh = (x[h] - gm[0][None, :, None, None]) / np.sqrt(gv[0] + eps)[None, :, None, None]
+        act = np.maximum(gamma[None, :, None, None] * xh + beta[None, :, None, None], 0)
+        g = np.where(act > 0, dy[h], 0).astype(np.float64)
+        dx = inv[None, :, None, None] * (g - s[0][Cc:][None, :, None, None] / M - xh * s[0][:Cc][None, :, None, None] / M)
+        assert rel_l2(dx, nchw_(odx[h])) <= 1e-4, "dx of replica %d: %.3e" % (r, rel_l2(dx, nchw_(odx[h])))
+
+
+def nchw_(a):
+    return np.ascontiguousarray(np.transpose(a, (0, 3, 1, 2)))

@@ -148,3 +148,26 @@ def test_reference_style_c_driver(tmp_path):
     losses = [float(x) for x in open(log).read().split()]
     assert len(losses) == 6 and all(np.isfinite(losses)) and [float(b) for _, b, _ in lines] == losses
     assert 6.0 < losses[0] < 8.0  # ln(1000) = 6.9 at random init
+
+
+def test_c_driver_takes_iterations_per_epoch_from_the_class_counts(tmp_path):
+    """resnet.cu:3236-3242, 3309: total_images = sum of id_to_img_count_mapping.txt, iterations_per_epoch = ceil(total / BATCH_SIZE).
+    Three class files (labels / synsets / counts, one line per class), 1000 classes of which 21 hold one image, batch 8 ->
+    3 iterations per epoch; two epochs -> 6 iteration lines, the second epoch numbered from 0 again."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "ResNetMI")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "resnet_main.c"),
+                           "-L", os.path.join(root, "resnet_amd"), "-lresnet_mi", "-lm",
+                           "-Wl,-rpath," + os.path.join(root, "resnet_amd"), "-o", exe])
+    n_classes = 1000
+    (tmp_path / "labels.txt").write_text("".join("label %d\n" % i for i in range(n_classes)))
+    (tmp_path / "synsets.txt").write_text("".join("n%08d\n" % i for i in range(n_classes)))
+    (tmp_path / "counts.txt").write_text("1\n" * 21 + "0\n" * (n_classes - 21))
+    out = subprocess.check_output([exe, "--input", "32", "--blocks", "1", "--batch", "8", "--classes", str(n_classes), "--epochs", "2",
+                                   "--labels-file", str(tmp_path / "labels.txt"), "--synsets-file", str(tmp_path / "synsets.txt"),
+                                   "--counts-file", str(tmp_path / "counts.txt"), "--loss-log", str(tmp_path / "log.txt")], timeout=300).decode()
+    assert "class metadata: 1000 classes, 21 images" in out and "iterations per epoch: 3" in out
+    lines = re.findall(r"Epoch: (\d+), Batch: (\d+) -----", out)
+    assert [(int(a), int(b)) for a, b in lines] == [(0, 0), (0, 1), (0, 2), (1, 0), (1, 1), (1, 2)]

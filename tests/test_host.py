@@ -146,6 +146,54 @@ def test_dp_bucket_plan_resnet50_32mb():
     assert all(a[0] == b[1] for a, b in zip(plan2, plan2[1:]))
 
 
+def test_dp_bucket_plan_more_cuts_than_event_slots():
+    """a network with more cut points than bucket slots (MI_MAX_BUCKETS = 64, one event each): 70 blocks and 1-byte buckets would
+    cut 72 times.  The plan keeps the last slot for the forced final cut, so the tail of the arena goes out as ONE larger bucket --
+    still an exact tiling, no range lost (a lost range would silently miss its Adam step)."""
+    import synth
+    from resnet_amd import binding as B
+    lib = B.load()
+    dims = synth.resnet_dims(input=32, n_conv_blocks=70, reductions=(), final_depth=256)
+    import ctypes as C
+    flags = (C.c_int * 70)(*dims["is_block_spatial_reduction"])
+    d = lib.init_dimensions(dims["input"], 7, 64, 2, 3, 2, 70, flags, 256, dims["output"])
+    fr, to = (C.c_size_t * 128)(), (C.c_size_t * 128)()
+    n = lib.mi_debug_dp_plan(d, 1, fr, to, 128)
+    arena = int(lib.mi_debug_arena_floats(d))
+    plan = [(int(fr[i]), int(to[i])) for i in range(n)]
+    assert n == 64, n
+    assert plan[0][1] == arena and plan[-1][0] == 0
+    assert all(a[0] == b[1] and b[0] < a[0] for a, b in zip(plan, plan[1:]))
+    offs, _, total = _arena_offsets(dims)
+    assert total == arena and all(f in offs for f, _ in plan)
+    assert plan[-1][1] - plan[-1][0] > plan[-2][1] - plan[-2][0]  # the merged tail: several blocks + the stem
+
+
+def test_bench_self_launch_dry_run():
+    """`python bench.py --gpus N` with no launcher around it starts N fresh rank processes itself BEFORE anything touches a GPU
+    (the library is not even loaded in the parent).  --launch-dry-run prints what it would start: N workers running this script
+    with the same arguments, RANK / LOCAL_RANK = 0..N-1, WORLD_SIZE = N, one rendezvous address for all, dmabuf IPC on."""
+    import json
+    for n in (2, 8):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "7", "--warmup", "2", "--launch-dry-run"],
+                           capture_output=True, text=True, timeout=120, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        assert d["n_workers"] == n and d["touches_gpu"] is False and len(d["workers"]) == n
+        ports = set()
+        for i, w in enumerate(d["workers"]):
+            e = w["env"]
+            assert (e["RANK"], e["LOCAL_RANK"], e["WORLD_SIZE"]) == (str(i), str(i), str(n))
+            assert e["MASTER_ADDR"] == "127.0.0.1" and e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+            ports.add(e["MASTER_PORT"])
+            assert w["cmd"][1].endswith("bench.py") and "--launch-dry-run" not in w["cmd"]
+            assert w["cmd"][2:] == ["--gpus", str(n), "--steps", "7", "--warmup", "2"]
+        assert len(ports) == 1
+    # the parent of a real launch must not have loaded the HIP library: bench.py imports resnet_amd only in the worker path
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.index("sys.exit(launch_workers(args, argv))") < src.index("lib = B.load()")
+
+
 DP_WORKER = r"""
 import os, sys
 import numpy as np

@@ -8,7 +8,7 @@ OUT=$REPO/gpurun_out/pmc_traffic_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/$c" -o run -- python3 "$REPO/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-prof --no-extra $BENCH_ARGS > "$OUT/$c.log" 2> "$OUT/$c.err" || exit 1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/$c" -o run -- python3 "$REPO/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-prof --no-extra --no-bf16 $BENCH_ARGS > "$OUT/$c.log" 2> "$OUT/$c.err" || exit 1
 done
 python3 - "$OUT" "$REPO/gpurun_out/pmc_traffic_$TAG.json" <<'PY'
 import csv, glob, json, sys, collections
@@ -36,8 +36,11 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         agg[k][c] += float(r["Counter_Value"]) * 1024.0  # counter unit: KB
         if c == "FETCH_SIZE" and r["Dispatch_Id"] not in seen:
             seen.add(r["Dispatch_Id"]); agg[k]["launches"] += 1
-res = {"source": "tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes (with --kernel-trace only) over "
-                 "`python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof --no-extra %s` (2 training steps each pass)" % __import__("os").environ.get("BENCH_ARGS", ""),
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(dst)))
+import bench
+res = {"source_sha16": bench.source_sha16(),
+       "source": "tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes (with --kernel-trace only) over "
+                 "`python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof --no-extra --no-bf16 %s` (2 training steps each pass)" % __import__("os").environ.get("BENCH_ARGS", ""),
        "unit_note": "counter values are KB; bytes = value*1024. MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide "
                     "(16 B/lane) coalesced stream; other access widths are uncalibrated (raw value reported, doubled value = upper bound). "
                     "Infinity-Cache hits are counted, not excluded.",

@@ -6,7 +6,7 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/raw" -o run -- python3 "$REPO/bench.py" --no-cpu-baseline --no-extra --steps 10 --warmup 3 $BENCH_ARGS > "$OUT/bench.json" 2> "$OUT/rocprof.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/raw" -o run -- python3 "$REPO/bench.py" --no-cpu-baseline --no-extra --no-bf16 --steps 10 --warmup 3 $BENCH_ARGS > "$OUT/bench.json" 2> "$OUT/rocprof.err"
 rc=$?
 f=$(find "$OUT/raw" -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp "$f" "$OUT/kernel_stats.csv"
