@@ -319,10 +319,12 @@ LOSS_ABS_BF16 = 5e-2
 # Gradients: bf16 storage flips the ReLU gate of every pre-activation that lies within its rounding of 0 (~0.3 % of the
 # elements of a layer here), and one flipped gate is an O(1) change of that element's gradient: a float64 model that only
 # ROUNDS the stored tensors to bf16 (torch_ref.TorchNetBF16) is 6-25 % (rel-L2) away from the exact gradient on these
-# nets, and two such executions differ from each other by as much.  The test therefore bounds the product's deviation from
-# the fp32 oracle by that inherent level: per tensor <= 1.5 x the emulation's deviation + 1e-2, and <= 0.35 outright;
-# the FC gradient (one bf16 tensor away from fp32) <= 1e-2.
-GRAD_REL_CAP = 0.35
+# nets, and two such executions differ from each other by as much.  So the gates are taken OUT of the comparison: the model
+# is run with the product's own discrete decisions (the signs of its stored activations, its max-pool positions:
+# torch_ref.gates_of), and the product's gradients must agree with that model's to GRAD_REL_SHARED_GATES -- rounding alone.
+# The distance to the fp32 oracle (gates included) is printed, not asserted; the FC gradient (one bf16 tensor away from
+# fp32, no gate in between) is held to 1e-2 against the oracle directly.
+GRAD_REL_SHARED_GATES = 5e-2
 GRAD_FC_REL = 1e-2
 
 
@@ -379,27 +381,25 @@ def test_training_step_bf16_vs_fp32_oracle(oracle, cfg):
             (gl, _), (ol, _) = tr.loss(), net.loss()
             worst["loss"] = max(worst["loss"], abs(gl - ol))
             assert abs(gl - ol) <= LOSS_ABS_BF16, (gl, ol)
-            # the inherent level: float64 arithmetic, bf16 rounding of the stored tensors only, same parameters and batch
-            emu = torch_ref.TorchNetBF16(dims, [net.param(i).copy() for i in range(net.n_locations)], eps=HYPER["eps"])
+            # float64 arithmetic, bf16 rounding at the product's storage points, the product's own gates: same parameters and batch
+            emu = torch_ref.TorchNetBF16(dims, [net.param(i).copy() for i in range(net.n_locations)], eps=HYPER["eps"], gates=torch_ref.gates_of(tr, dims))
             emu.forward(torch_ref.nhwc_to_nchw(im), lab)
             emu_grads = emu.backward()
             net.backward()
             tr.backward()
             tr.check()
             for i in range(net.n_locations):
-                ref = net.grad(i)
-                r = rel_l2(tr.get("grads", i), ref)
-                e = rel_l2(emu_grads[i].reshape(-1), ref)
+                got = tr.get("grads", i)
+                r = rel_l2(got, emu_grads[i].reshape(-1))
                 worst["grad"] = max(worst["grad"], r)
-                worst["ratio"] = max(worst["ratio"], r / (e + 1e-2))
-                cap = GRAD_REL_CAP + (0.1 if dims["n_conv_blocks"] > 3 else 0.0)  # (the inherent level grows with depth: 0.32 for the 4-block net)
-                assert r <= cap and r <= 1.5 * e + 1e-2, "gradient %d step %d: rel-L2 %.3e (bf16-rounded float64 model: %.3e)" % (i, step, r, e)
+                worst["ratio"] = max(worst["ratio"], rel_l2(got, net.grad(i)))
+                assert r <= GRAD_REL_SHARED_GATES, "gradient %d step %d: rel-L2 %.3e against the bf16-rounding model run with the product's gates" % (i, step, r)
             assert rel_l2(tr.get("grads", net.n_locations - 1), net.grad(net.n_locations - 1)) <= GRAD_FC_REL * (1.5 if dims["n_conv_blocks"] > 3 else 1.0)
             net.update()
             tr.update()
             assert tr.check_errors() == 0
-        print("bf16 %s: worst activation rel-L2 %.3e, loss |d| %.3e, gradient rel-L2 %.3e (%.2f x the inherent level)"
-              % (cfg, worst["act"], worst["loss"], worst["grad"], worst["ratio"]))
+        print("bf16 %s: worst activation rel-L2 %.3e, loss |d| %.3e; gradients: %.3e from the rounding model with shared gates (asserted), "
+              "%.3e from the fp32 oracle with its own gates (printed only)" % (cfg, worst["act"], worst["loss"], worst["grad"], worst["ratio"]))
     finally:
         tr.close()
         net.close()
@@ -504,19 +504,18 @@ def test_resnet50_bf16_every_block_and_both_bn_backward_routes(oracle):
             tr.set_params(params)
             tr.source_host(B.MI_LAYOUT_NHWC)
             tr.fill_host_batch(im, lab); tr.load_new_batch(); tr.forward(); tr.check()
-            if check_forward:
-                check_forward(tr, im, lab)
+            extra = check_forward(tr, im, lab) if check_forward else None
             tr.backward(); tr.check()
-            return [tr.get("grads", i).copy() for i in range(tr.n_locations)]
+            return [tr.get("grads", i).copy() for i in range(tr.n_locations)], extra
         finally:
             tr.close()
             os.environ.pop("RESNET_MI_BF16_BNFUSE_BWD", None)
 
     def forward_checks(tr, im, lab):
-        # Batch 2 through 16 blocks (BN over 98-6272 samples amplifies every rounding).  The yardstick: float64 arithmetic with bf16
-        # rounding at exactly the product's storage points.  Against the fp32 oracle both sit at the same, inherent, distance
-        # (1e-2 after block 0 ... 0.48 after block 15 on this net); two executions of the rounding rule differ from each other by
-        # about half of it (values on a rounding boundary).
+        # 16 blocks of batch norm amplify every rounding (at batch 2: BN over 98-6272 samples).  The yardstick: float64 arithmetic with
+        # bf16 rounding at exactly the product's storage points.  Against the fp32 oracle both sit at the same, inherent, distance
+        # (batch 2: 1e-2 after block 0 ... 0.48 after block 15); two executions of the rounding rule differ from each other by about
+        # half of it (values on a rounding boundary).  Returns the gradients of the rounding model run with the product's gates.
         batch = len(lab)
         net = OracleNet(oracle, dims, batch)
         try:
@@ -530,16 +529,28 @@ def test_resnet50_bf16_every_block_and_both_bn_backward_routes(oracle):
                 nm = "conv_blocks/%02d/output_activated" % b
                 g, m = tr.activation(nm), emu.acts["b%d_out" % b].detach().numpy()
                 r_or, r_em, e_or = rel_l2(nhwc(g), net.tensor(nm)), rel_l2(g, m), rel_l2(nhwc(m.astype(np.float32)), net.tensor(nm))
-                print("  block %2d output: HIP vs rounding model %.2e; vs the fp32 oracle: HIP %.2e, rounding model %.2e" % (b, r_em, r_or, e_or))
+                print("  batch %d block %2d output: HIP vs rounding model %.2e; vs the fp32 oracle: HIP %.2e, rounding model %.2e" % (batch, b, r_em, r_or, e_or))
                 assert r_em <= e_or + 2e-3, "block %d output: rel-L2 %.3e against the bf16-rounding model (its own deviation %.3e)" % (b, r_em, e_or)
                 assert r_or <= 1.5 * e_or + 5e-3, "block %d output: %.3e from the fp32 oracle, the rounding model is %.3e" % (b, r_or, e_or)
+            del emu
         finally:
             net.close()
+        shared = torch_ref.TorchNetBF16(dims, params, eps=HYPER["eps"], gates=torch_ref.gates_of(tr, dims))
+        shared.forward(torch_ref.nhwc_to_nchw(im), lab)
+        return [g.reshape(-1).copy() for g in shared.backward()]
 
     run(2, 1, forward_checks)
+    # batch 8: every block's output against the fp32 oracle and the rounding model (above), and the gradients of all 160 tensors
+    # against the rounding model run with the product's OWN gates (signs of its stored activations, its max-pool positions): with
+    # the discrete decisions shared, what is left is rounding, amplified by 53 BN layers -- not gate flips
+    g1, shared = run(8, 1, forward_checks)
+    errs = [rel_l2(a, b) for a, b in zip(g1, shared)]
+    print("  gradients at batch 8 vs the bf16-rounding model with the product's gates: worst rel-L2 %.2e (location %d), median %.2e"
+          % (max(errs), int(np.argmax(errs)), float(np.median(errs))))
+    assert max(errs) <= GRAD_REL_SHARED_GATES, "location %d: %.3e" % (int(np.argmax(errs)), max(errs))
     # the two BN-backward routes (reductions in the dgrad epilogues / as passes of their own) at batch 8: same gates, fp32 sums in
     # another order -- a bf16 tensor downstream of a sum may flip a last bit, and 16 blocks of batch norm amplify that
-    g1, g0 = run(8, 1, None), run(8, 0, None)
+    g0, _ = run(8, 0, None)
     errs = [rel_l2(a, b) for a, b in zip(g1, g0)]
     print("  gradients, BN' reductions in the dgrad epilogues vs as passes of their own (batch 8): worst rel-L2 %.2e (location %d), median %.2e"
           % (max(errs), int(np.argmax(errs)), float(np.median(errs))))

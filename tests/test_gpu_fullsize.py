@@ -7,6 +7,8 @@ the reference-defined ResNet-50, fp32, 224x224, batch 256, and the network's own
   * directional finite differences of the batch-sum loss against the analytic gradients (layers after the max-pool;
     the reference's overwrite max-pool backward is not the exact gradient, so the stem is excluded)
   * bitwise run-to-run determinism; Adam's first step moves every weight by at most lr; gradients zeroed afterwards
+The whole-network properties run for both storage types (fp32, bf16 activations = BASELINE configs[4]) and both store policies
+(FAST, RECOMPUTE_BN) at batch 256; the adjoint identities also on the bf16 operators (mi_op_conv_*_bf16).
 """
 import ctypes as C
 
@@ -55,14 +57,54 @@ def test_conv_adjoint_identities_and_homogeneity(ops, shape):
     assert np.array_equal(y2.get(), 2.0 * hy)
 
 
-@pytest.fixture(scope="module")
-def r50():
+def _bf16_round(a):
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32)
+    r = ((u >> np.uint32(16)) & np.uint32(1)) + np.uint32(0x7FFF)
+    return ((u + r) & np.uint32(0xFFFF0000)).view(np.float32)
+
+
+@pytest.mark.parametrize("shape", ADJ_SHAPES, ids=["C%d_H%d_K%d_k%d_s%d" % s for s in ADJ_SHAPES])
+def test_conv_adjoint_identities_bf16_operators(ops, shape):
+    """the same identities on the bf16 operators at batch 32: x, dy and w bf16-representable (so the kernels' own rounding of the
+    weights is exact), y and dx come back ROUNDED to bf16, dw in fp32.  A rounded output carries independent relative errors of
+    2^-9 per element: <y, dy> is then off by ~2^-9 |y||dy| / sqrt(n) (n >= 1.6e5 here: < 1.5e-5 of the scale); band 5e-5."""
+    Cc, H, K, k, s = shape
+    N, Ho = 32, H // s
+    rng = np.random.RandomState(5)
+    x = _bf16_round(rng.uniform(-1, 1, (N, Cc, H, H)).astype(np.float32))
+    w = _bf16_round(rng.uniform(-0.05, 0.05, (K, Cc, k, k)).astype(np.float32))
+    dy = _bf16_round(rng.uniform(-1, 1, (N, K, Ho, Ho)).astype(np.float32))
+    y = ops.conv_fwd_bf16(x, w, s)
+    dx = ops.conv_dgrad_bf16(w, dy, H, s)
+    dw = ops.conv_wgrad_bf16(x, dy, k, s)
+    a = float(np.vdot(y.astype(np.float64), dy.astype(np.float64)))
+    b = float(np.vdot(x.astype(np.float64), dx.astype(np.float64)))
+    c = float(np.vdot(w.astype(np.float64), dw.astype(np.float64)))
+    scale = float(np.linalg.norm(y.astype(np.float64)) * np.linalg.norm(dy.astype(np.float64)))
+    assert abs(a - c) <= 5e-5 * scale and abs(b - c) <= 5e-5 * scale, (a, b, c, scale)
+    # homogeneity survives the rounding: 2w is as representable as w, every product and partial sum doubles exactly
+    assert np.array_equal(ops.conv_fwd_bf16(x, (2.0 * w).astype(np.float32), s), 2.0 * y)
+
+
+F32, BF16 = 0, 1
+FAST, RECOMPUTE_BN = 0, 1
+COMBOS = [(F32, FAST), (F32, RECOMPUTE_BN), (BF16, FAST), (BF16, RECOMPUTE_BN)]
+
+
+@pytest.fixture(scope="module", params=COMBOS, ids=["f32-fast", "f32-recompute_bn", "bf16-fast", "bf16-recompute_bn"])
+def r50(request):
     from resnet_amd import Trainer
+    dtype, policy = request.param
     tr = Trainer(synth.R50_DIMS, 256, lr=1e-4, seed=1236)
     if tr.L.mi_device_count() < 1:
         pytest.fail("needs the MI355X box")
+    if policy != FAST:
+        tr.set_store_policy(policy)
+    if dtype != F32:
+        tr.set_dtype(dtype)
     tr.source_synthetic(1234, 1235, pool_batches=1)
     tr.L.mi_trainer_set_input_reset(tr.t, 0)
+    tr.combo = (dtype, policy)
     yield tr
     tr.close()
 
@@ -74,6 +116,7 @@ def _loss64(tr):
 
 def test_fullsize_forward_properties(r50):
     tr = r50
+    dtype, policy = tr.combo
     tr.load_new_batch(); tr.forward(); tr.check()
     p = tr.pred()
     assert np.all(np.isfinite(p)) and np.allclose(p.sum(axis=1), 1.0, atol=1e-5)
@@ -84,15 +127,26 @@ def test_fullsize_forward_properties(r50):
               "init_conv_applied": "batch_norms/init"}[name]
         m, v = tr.activation(bn + "/means"), tr.activation(bn + "/vars")
         rm, rv = x.mean(axis=(0, 2, 3)), x.var(axis=(0, 2, 3))  # biased variance, as resnet.cu:321
-        assert np.allclose(m, rm, rtol=1e-5, atol=1e-6 * np.abs(rm).max()), name
-        assert np.allclose(v, rv, rtol=2e-5), name
+        if dtype == F32 or name == "init_conv_applied":  # (the stem convolution's own output is an fp32 tensor in both storage types)
+            assert np.allclose(m, rm, rtol=1e-5, atol=1e-6 * np.abs(rm).max()), name
+            assert np.allclose(v, rv, rtol=2e-5), name
+        else:
+            # bf16 storage: the statistics are taken from the convolution's fp32 accumulators, the stored tensor is their rounding
+            # (relative error <= 2^-9 per element, independent): over >= 12544 samples a mean moves by < 2^-9 * rms / sqrt(M) * few,
+            # a variance by a few 1e-4 relative
+            rms = np.sqrt(rv + rm * rm)
+            assert np.all(np.abs(m - rm) <= 2.0 ** -9 * rms * 0.1 + 1e-6 * np.abs(rm).max()), (name, float(np.max(np.abs(m - rm) / rms)))
+            assert np.allclose(v, rv, rtol=2e-3), (name, float(np.max(np.abs(v - rv) / rv)))
     for b in (0, 3, 15):
         assert tr.activation("conv_blocks/%02d/output_activated" % b).min() >= 0.0
     # max-pool: arg-max inside the 3x3/s2 window centred at 2*o and holding the pooled value
-    xin, idx, y = tr.activation("init_conv_activated"), tr.activation("max_inds"), tr.activation("init_convblock_input")
-    assert np.array_equal(xin.ravel()[idx.ravel()], y.ravel())
+    idx, y = tr.activation("max_inds"), tr.activation("init_convblock_input")
+    if policy == FAST:  # (RECOMPUTE_BN keeps the stem's BN+ReLU output in a scratch buffer that later layers reuse)
+        xin = tr.activation("init_conv_activated")
+        assert np.array_equal(xin.ravel()[idx.ravel()], y.ravel())
+    assert y.min() >= 0.0
     N, Cc, Ho, _ = y.shape
-    H = xin.shape[2]
+    H = synth.R50_DIMS["input"] // synth.R50_DIMS["init_conv_stride"]
     pos = idx - (np.arange(N)[:, None, None, None] * Cc + np.arange(Cc)[None, :, None, None]) * H * H
     ih, iw = pos // H, pos % H
     oh, ow = np.arange(Ho)[None, None, :, None], np.arange(Ho)[None, None, None, :]
@@ -101,6 +155,7 @@ def test_fullsize_forward_properties(r50):
 
 def test_fullsize_gradient_finite_differences_and_determinism(r50):
     tr = r50
+    dtype, policy = tr.combo
     tr.load_new_batch(); tr.forward(); tr.backward(); tr.check()
     n_loc = tr.n_locations
     grads_a = {i: tr.get("grads", i) for i in (n_loc - 1, n_loc - 4, 30, 5)}
@@ -116,8 +171,11 @@ def test_fullsize_gradient_finite_differences_and_determinism(r50):
         assert gn > 0
         theta = tr.get("params", i)
         # expected |dL| = 2*eps*|g| on a loss of ~1.8e3: above fp32 noise (~2e-3); the early layer sits under 50 ReLU/BN
-        # layers (strong curvature), so it takes a smaller step and a wider band
-        eps = (0.5 if i > 20 else 0.1) / gn
+        # layers (strong curvature), so it takes a smaller step and a wider band.  bf16 storage: every stored tensor between the
+        # perturbed weight and the loss re-rounds under the perturbation (a pseudo-random 2^-9 relative change per element); the FC
+        # layer has no bf16 tensor downstream of it and keeps the fp32 band, the convolutions take a 4x larger step and a wider band
+        bf_conv = dtype == BF16 and i != n_loc - 1
+        eps = (0.5 if i > 20 else 0.1) * (4.0 if bf_conv else 1.0) / gn
         v = g / gn
         losses = []
         for sgn in (+1, -1):
@@ -126,7 +184,9 @@ def test_fullsize_gradient_finite_differences_and_determinism(r50):
             losses.append(_loss64(tr))
         tr.set("params", i, theta)
         fd = (losses[0] - losses[1]) / (2 * eps)
-        assert abs(fd - gn) <= (0.03 if i > 20 else 0.06) * gn, "location %d: finite difference %.5g vs |grad| %.5g" % (i, fd, gn)
+        band = (0.03 if i > 20 else 0.06) * (4.0 if bf_conv else 1.0)
+        print("  %s location %d: finite difference %.5g, |grad| %.5g (%.2f %% apart, band %.0f %%)" % (["f32", "bf16"][dtype], i, fd, gn, 100 * abs(fd - gn) / gn, 100 * band))
+        assert abs(fd - gn) <= band * gn, "location %d: finite difference %.5g vs |grad| %.5g" % (i, fd, gn)
 
 
 def test_fullsize_adam_step(r50):

@@ -11,7 +11,22 @@ from util import ACT_MAX_ABS, ACT_REL_L2, GRAD_REL_L2, LOSS_ABS, check_act, chec
 
 pytestmark = pytest.mark.gpu
 
-PARAM_REL_L2 = 2e-5  # after an Adam step (~lr * sign(g) at first: gradient elements near 0 amplify rounding; measured 1.2e-5 worst)
+# Adam itself is pinned in tests/test_gpu_state.py::test_adam_pinned_with_the_oracles_gradients (the oracle's gradients injected:
+# parameters / moments at 1e-6).  End to end the first Adam steps are ~lr * sign(g), so an element whose gradient is at rounding
+# level (|g| <~ eps = 1e-7 ... 1e-6) turns a 1e-7 gradient difference into an lr-sized parameter difference: gradient-sign noise,
+# not Adam.  The whole-step check therefore compares the parameters where the gradient is RESOLVED (|g| above 1e-3 of the tensor's
+# rms; >= 90 % of every tensor) at 1e-6, and all of them at the loose PARAM_REL_L2.
+PARAM_REL_L2 = 2e-5
+PARAM_REL_L2_RESOLVED = 1e-6
+
+
+def check_params_after_update(got, ref, ref_grad, what):
+    g = np.abs(np.asarray(ref_grad, np.float64).ravel())
+    mask = g > 1e-3 * np.sqrt(np.mean(g * g) + 1e-300)
+    assert mask.mean() >= 0.9, "%s: only %.0f %% of the gradient elements are resolved" % (what, 100 * mask.mean())
+    r = rel_l2(np.asarray(got).ravel()[mask], np.asarray(ref).ravel()[mask])
+    assert r <= PARAM_REL_L2_RESOLVED, "%s (elements with a resolved gradient): rel-L2 %.3e" % (what, r)
+    assert rel_l2(got, ref) <= PARAM_REL_L2, "%s: rel-L2 %.3e" % (what, rel_l2(got, ref))
 HYPER = dict(lr=1e-4, wd=0.0, b1=0.9, b2=0.999, eps=1e-7)
 
 
@@ -121,6 +136,7 @@ def test_training_step_parity(oracle, oracle64, cfg):
                 check_grad(tr.get("grads", i), ref.grad(i), "gradient of location %d step %d%s" % (i, step, " (f64 oracle)" if disputed else ""),
                            rel=tol if flips == 0 else 3e-2)
             # ---- Adam ----
+            ref_grads = [ref.grad(i).copy() for i in range(net.n_locations)]
             net.update()
             ref64.update()
             tr.update()
@@ -128,7 +144,7 @@ def test_training_step_parity(oracle, oracle64, cfg):
             for i in range(net.n_locations):
                 if flips == 0:  # (with a flipped gate the gradients fed to Adam differ: the update is pinned by the other steps)
                     # Adam's first steps are ~lr*sign(g): gradient elements near 0 amplify rounding differences
-                    assert rel_l2(tr.get("params", i), ref.param(i)) <= PARAM_REL_L2, "param %d" % i
+                    check_params_after_update(tr.get("params", i), ref.param(i), ref_grads[i], "param %d step %d" % (i, step))
                     check_grad(tr.get("means", i), ref.mean(i), "adam mean %d" % i)
                     check_grad(tr.get("vars", i), ref.var(i), "adam var %d" % i, rel=2 * GRAD_REL_L2)
                 assert not np.any(tr.get("grads", i)), "gradients are zeroed after the update (resnet.cu:2972-2978)"
@@ -185,8 +201,6 @@ def test_synthetic_source_and_reproducibility():
             tr.forward(); run.append(tr.loss()[0]); tr.backward(); tr.update(); tr.load_new_batch()
         tr.check()
         losses.append(run)
-        # weights come from the same counter stream as tests/synth.make_params
-        assert np.allclose(Trainer.get(tr, "means", 0), Trainer.get(tr, "means", 0))
         tr.close()
     assert losses[0] == losses[1], "bitwise reproducible (no atomics, fixed reduction order)"
     assert all(np.isfinite(losses[0]))

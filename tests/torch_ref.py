@@ -23,8 +23,12 @@ class MaxPoolOverwrite(torch.autograd.Function):
     """3x3/s2/p1 max-pool whose backward overwrites instead of accumulating."""
 
     @staticmethod
-    def forward(ctx, x, k, s):
+    def forward(ctx, x, k, s, given_idx=None):
         y, idx = F.max_pool2d(x, k, s, k // 2, return_indices=True)
+        if given_idx is not None:  # another execution's arg-max positions (per-plane flat indices): take ITS choices
+            idx = given_idx
+            N, C = x.shape[:2]
+            y = x.reshape(N, C, -1).gather(2, idx.reshape(N, C, -1)).reshape(idx.shape)
         ctx.save_for_backward(idx)
         ctx.shape = x.shape
         return y
@@ -37,7 +41,7 @@ class MaxPoolOverwrite(torch.autograd.Function):
         idx2, dy2 = idx.reshape(N, C, -1), dy.reshape(N, C, -1)
         for j in range(idx2.shape[2]):  # (oh, ow) scan order: later outputs overwrite earlier ones
             dx.scatter_(2, idx2[:, :, j:j + 1], dy2[:, :, j:j + 1])
-        return dx.reshape(N, C, H, W), None, None
+        return dx.reshape(N, C, H, W), None, None, None
 
 
 def bn_train(x, g, b, eps):
@@ -124,7 +128,21 @@ class _RoundBF16(torch.autograd.Function):
 
 
 class TorchNetBF16(TorchNet):
-    def _unit(self, x, i, K, C, k, stride, relu, name, residual=None):
+    """gates (optional): the DISCRETE decisions of another execution of the same step -- {name: bool NCHW array} for every ReLU
+    ("stem", "b%d_red", "b%d_spa", "b%d_out": that execution's stored activation > 0) and "max_inds" (its per-plane arg-max
+    positions).  With them the model takes those decisions instead of its own, so the two executions' gradients differ by
+    rounding alone: a pre-activation within bf16 rounding of 0 no longer shows up as an O(1) difference of that element."""
+
+    def __init__(self, dims, params, eps=1e-7, dtype=torch.float64, gates=None):
+        super().__init__(dims, params, eps, dtype)
+        self.gates = gates
+
+    def _relu(self, z, key):
+        if self.gates is None:
+            return F.relu(z)
+        return z * torch.tensor(np.asarray(self.gates[key]), dtype=z.dtype)
+
+    def _unit(self, x, i, K, C, k, stride, relu, name, residual=None, key=None):
         w = self.p[i].view(K, C, k, k)
         stem = name == "stem"
         w = w + (_rb(w.detach()) - w.detach())  # rounded value, gradient to the fp32 master copy
@@ -135,9 +153,9 @@ class TorchNetBF16(TorchNet):
             y = _RoundBF16.apply(y)
         z = bn_train(y, self.p[i + 1], self.p[i + 2], self.eps)
         if residual is not None:
-            z = F.relu(z + residual)  # BN + addVec + doActivation are one kernel: one rounding
+            z = self._relu(z + residual, key)  # BN + addVec + doActivation are one kernel: one rounding
         elif relu:
-            z = F.relu(z)
+            z = self._relu(z, key)
         return _RoundBF16.apply(z)
 
     def forward(self, images_nchw, labels):
@@ -145,21 +163,22 @@ class TorchNetBF16(TorchNet):
         x = torch.tensor(images_nchw, dtype=self.p[0].dtype)
         f = d["init_conv_filters"]
         li = 0
-        x = self._unit(x, li, f, 3, d["init_kernel_dim"], d["init_conv_stride"], True, "stem")
+        x = self._unit(x, li, f, 3, d["init_kernel_dim"], d["init_conv_stride"], True, "stem", key="stem")
         li += 3
-        x = MaxPoolOverwrite.apply(x, d["init_maxpool_dim"], d["init_maxpool_stride"])
+        given = None if self.gates is None else torch.tensor(np.asarray(self.gates["max_inds"]), dtype=torch.long)
+        x = MaxPoolOverwrite.apply(x, d["init_maxpool_dim"], d["init_maxpool_stride"], given)
         inc, red, ex = f, f, 4 * f
         for b in range(d["n_conv_blocks"]):
             stride = 1
             if d["is_block_spatial_reduction"][b]:
                 stride, red, ex = 2, red * 2, ex * 2
-            r = self._unit(x, li, red, inc, 1, 1, True, "red"); li += 3
-            s = self._unit(r, li, red, red, 3, stride, True, "spa"); li += 3
+            r = self._unit(x, li, red, inc, 1, 1, True, "red", key="b%d_red" % b); li += 3
+            s = self._unit(r, li, red, red, 3, stride, True, "spa", key="b%d_spa" % b); li += 3
             le = li; li += 3
             res = x
             if inc != ex:
                 res = self._unit(x, li, ex, inc, 3 if stride == 2 else 1, stride, False, "proj"); li += 3
-            x = self._unit(s, le, ex, red, 1, 1, False, "exp", residual=res)
+            x = self._unit(s, le, ex, red, 1, 1, False, "exp", residual=res, key="b%d_out" % b)
             self.acts["b%d_out" % b] = x
             inc = ex
         pooled = x.mean(dim=(2, 3))
@@ -168,3 +187,17 @@ class TorchNetBF16(TorchNet):
         lab = torch.tensor(np.asarray(labels), dtype=torch.long)
         self.loss = -torch.log(self.pred[torch.arange(len(lab)), lab]).sum()
         return self.loss
+
+
+def gates_of(tr, dims):
+    """the discrete decisions of a product forward pass (resnet_amd.Trainer after forward_pass), as TorchNetBF16(gates=...) takes them"""
+    g = {"stem": tr.activation("init_conv_activated") > 0}
+    mi = tr.activation("max_inds").astype(np.int64)  # flat NCHW indices into the stem's output tensor
+    N, C, Hp, _ = mi.shape
+    Hs = dims["input"] // dims["init_conv_stride"]
+    g["max_inds"] = mi - ((np.arange(N)[:, None, None, None] * C + np.arange(C)[None, :, None, None]) * Hs * Hs)
+    for b in range(dims["n_conv_blocks"]):
+        g["b%d_red" % b] = tr.activation("conv_blocks/%02d/reduction_activated" % b) > 0
+        g["b%d_spa" % b] = tr.activation("conv_blocks/%02d/spatial_activated" % b) > 0
+        g["b%d_out" % b] = tr.activation("conv_blocks/%02d/output_activated" % b) > 0
+    return g
