@@ -5,8 +5,12 @@
 
 void mi_record_error(const char *what, const char *detail);
 
+// diagnostic (RESNET_MI_TRACE=1): the names of the last launches, printed when the process is aborted (a GPU memory fault reaches
+// the host as SIGABRT from the runtime's event thread, with nothing that names the kernel)
+void mi_trace_launch(const char *name);
 #define MI_LAUNCH_CHECK(name)                                              \
     do {                                                                   \
+        mi_trace_launch(name);                                             \
         hipError_t e_ = hipGetLastError();                                 \
         if (e_ != hipSuccess) { mi_record_error(name, hipGetErrorString(e_)); return -1; } \
     } while (0)

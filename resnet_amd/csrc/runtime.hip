@@ -5,12 +5,46 @@
 #include <dlfcn.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include "mi_device.h"
 #include "mi_common.hpp"
 
 static char g_err[512] = "";
 void mi_record_error(const char *what, const char *detail) {
     if (g_err[0] == 0) snprintf(g_err, sizeof g_err, "%s: %s", what, detail);
+}
+// ---- launch trace (diagnostic, off unless RESNET_MI_TRACE=1) ----
+#include <signal.h>
+#include <unistd.h>
+#define MI_TRACE_N 96
+static const char *g_trace[MI_TRACE_N];
+static unsigned g_trace_n = 0;
+static int g_trace_on = -1;
+static void (*g_trace_prev)(int) = SIG_DFL; /* e.g. Python's faulthandler: runs after the dump */
+static void mi_trace_dump(int sig) {
+    const char hdr[] = "\nresnet_mi: aborted; last kernel launches, oldest first:\n";
+    if (write(2, hdr, sizeof hdr - 1) < 0) {}
+    const unsigned n = g_trace_n < MI_TRACE_N ? g_trace_n : MI_TRACE_N;
+    for (unsigned i = 0; i < n; i++) {
+        const char *s = g_trace[(g_trace_n - n + i) % MI_TRACE_N];
+        if (s && (write(2, "  ", 2) < 0 || write(2, s, strlen(s)) < 0 || write(2, "\n", 1) < 0)) {}
+    }
+    signal(sig, g_trace_prev == SIG_IGN || g_trace_prev == SIG_ERR ? SIG_DFL : g_trace_prev);
+    raise(sig);
+}
+void mi_trace_launch(const char *name) {
+    if (g_trace_on < 0) {
+        const char *e = getenv("RESNET_MI_TRACE");
+        g_trace_on = e && atoi(e) ? 1 : 0;
+    }
+    if (!g_trace_on) return;
+    g_trace[g_trace_n++ % MI_TRACE_N] = name;
+    /* others (Python's faulthandler, test runners) install SIGABRT handlers of their own later on: stay in front of them */
+    struct sigaction cur;
+    if (sigaction(SIGABRT, NULL, &cur) == 0 && cur.sa_handler != mi_trace_dump) {
+        g_trace_prev = (cur.sa_flags & SA_SIGINFO) ? SIG_DFL : cur.sa_handler;
+        signal(SIGABRT, mi_trace_dump);
+    }
 }
 #define HIPCHK(x)                                                          \
     do {                                                                   \

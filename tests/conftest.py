@@ -9,6 +9,10 @@ for p in (ROOT, os.path.dirname(os.path.abspath(__file__))):
         sys.path.insert(0, p)
 
 
+# a GPU memory fault reaches the host as a bare SIGABRT: have the library name the last kernel launches when that happens
+os.environ.setdefault("RESNET_MI_TRACE", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -382,7 +382,8 @@ def test_training_step_bf16_vs_fp32_oracle(oracle, cfg):
             worst["loss"] = max(worst["loss"], abs(gl - ol))
             assert abs(gl - ol) <= LOSS_ABS_BF16, (gl, ol)
             # float64 arithmetic, bf16 rounding at the product's storage points, the product's own gates: same parameters and batch
-            emu = torch_ref.TorchNetBF16(dims, [net.param(i).copy() for i in range(net.n_locations)], eps=HYPER["eps"], gates=torch_ref.gates_of(tr, dims))
+            # (the PRODUCT's current parameters: after the first update they differ from the oracle's by up to 2 lr per element)
+            emu = torch_ref.TorchNetBF16(dims, [tr.get("params", i) for i in range(net.n_locations)], eps=HYPER["eps"], gates=torch_ref.gates_of(tr, dims))
             emu.forward(torch_ref.nhwc_to_nchw(im), lab)
             emu_grads = emu.backward()
             net.backward()
@@ -515,7 +516,7 @@ def test_resnet50_bf16_every_block_and_both_bn_backward_routes(oracle):
         # 16 blocks of batch norm amplify every rounding (at batch 2: BN over 98-6272 samples).  The yardstick: float64 arithmetic with
         # bf16 rounding at exactly the product's storage points.  Against the fp32 oracle both sit at the same, inherent, distance
         # (batch 2: 1e-2 after block 0 ... 0.48 after block 15); two executions of the rounding rule differ from each other by about
-        # half of it (values on a rounding boundary).  Returns the gradients of the rounding model run with the product's gates.
+        # half of it (values on a rounding boundary).
         batch = len(lab)
         net = OracleNet(oracle, dims, batch)
         try:
@@ -535,19 +536,45 @@ def test_resnet50_bf16_every_block_and_both_bn_backward_routes(oracle):
             del emu
         finally:
             net.close()
-        shared = torch_ref.TorchNetBF16(dims, params, eps=HYPER["eps"], gates=torch_ref.gates_of(tr, dims))
-        shared.forward(torch_ref.nhwc_to_nchw(im), lab)
-        return [g.reshape(-1).copy() for g in shared.backward()]
+        return None
 
     run(2, 1, forward_checks)
-    # batch 8: every block's output against the fp32 oracle and the rounding model (above), and the gradients of all 160 tensors
-    # against the rounding model run with the product's OWN gates (signs of its stored activations, its max-pool positions): with
-    # the discrete decisions shared, what is left is rounding, amplified by 53 BN layers -- not gate flips
-    g1, shared = run(8, 1, forward_checks)
-    errs = [rel_l2(a, b) for a, b in zip(g1, shared)]
-    print("  gradients at batch 8 vs the bf16-rounding model with the product's gates: worst rel-L2 %.2e (location %d), median %.2e"
+    # batch 8: every block's output against the fp32 oracle and the rounding model (above) -- and what that shows is that THIS network
+    # (random init, gamma ~ 1 on every residual branch) amplifies any perturbation by ~1.3x per block: two valid executions of the
+    # same rounding rule are 0.31 apart after block 15, at batch 2 and at batch 8 alike.  Gradients of such a forward pass cannot be
+    # compared element-wise at 5e-2 with or without shared gates (measured: 0.21 .. 0.58), so the gradient check of the 16-block net
+    # runs in the well-conditioned regime training actually uses -- small gamma on the last BN of every residual branch
+    # ("zero-init residual"; here 0.2), where a perturbation stays a perturbation -- with the product's OWN gates in the model:
+    # every kernel, every plane size, all 160 tensors, rounding alone.
+    g1, _ = run(8, 1, forward_checks)
+    table = synth.location_table(dims)
+    damped = [p.copy() for p in params]
+    li = 3
+    inc, ex = dims["init_conv_filters"], 4 * dims["init_conv_filters"]
+    for b in range(dims["n_conv_blocks"]):
+        if dims["is_block_spatial_reduction"][b]:
+            ex *= 2
+        assert table[li + 7][1] == "g"
+        damped[li + 7] = (0.2 * damped[li + 7]).astype(np.float32)  # gamma of the expansion BN
+        li += 12 if inc != ex else 9
+        inc = ex
+    params_default = params
+    params = damped
+
+    def shared_gate_model(tr, im, lab):
+        shared = torch_ref.TorchNetBF16(dims, params, eps=HYPER["eps"], gates=torch_ref.gates_of(tr, dims))
+        shared.forward(torch_ref.nhwc_to_nchw(im), lab)
+        out15 = rel_l2(tr.activation("conv_blocks/15/output_activated"), shared.acts["b15_out"].detach().numpy())
+        print("  damped residual branches, batch 8: last block output, HIP vs the rounding model with the product's gates: %.2e" % out15)
+        assert out15 <= 2e-2, out15
+        return [g.reshape(-1).copy() for g in shared.backward()]
+
+    gd, shared = run(8, 1, shared_gate_model)
+    errs = [rel_l2(a, b) for a, b in zip(gd, shared)]
+    print("  gradients at batch 8 (damped residual branches) vs the bf16-rounding model with the product's gates: worst rel-L2 %.2e (location %d), median %.2e"
           % (max(errs), int(np.argmax(errs)), float(np.median(errs))))
     assert max(errs) <= GRAD_REL_SHARED_GATES, "location %d: %.3e" % (int(np.argmax(errs)), max(errs))
+    params = params_default
     # the two BN-backward routes (reductions in the dgrad epilogues / as passes of their own) at batch 8: same gates, fp32 sums in
     # another order -- a bf16 tensor downstream of a sum may flip a last bit, and 16 blocks of batch norm amplify that
     g0, _ = run(8, 0, None)
