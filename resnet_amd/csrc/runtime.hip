@@ -36,6 +36,7 @@ void mi_trace_launch(const char *name) {
     if (g_trace_on < 0) {
         const char *e = getenv("RESNET_MI_TRACE");
         g_trace_on = e && atoi(e) ? 1 : 0;
+        if (g_trace_on && atoi(e) > 1) fprintf(stderr, "resnet_mi: launch trace on\n");
     }
     if (!g_trace_on) return;
     g_trace[g_trace_n++ % MI_TRACE_N] = name;
