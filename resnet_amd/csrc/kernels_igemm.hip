@@ -171,7 +171,10 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
         a_lane = (uint32_t)(a_k * Mdim + a_i) * 4u;
         const int j = VB ? n0 + (tid & 31) * 4 : n0 + (tid & 127);
         const bool jin = j < g.ncols; // VB: ncols % 4 == 0, the four columns are in or out together
-        const uint32_t jc = jin ? (uint32_t)j : (uint32_t)g.ncols - 1;
+        // columns past the end decode to a column that exists (masked below).  VB: to the START of the last group of four -- a 16-byte
+        // load from the last pixel itself would run 12 bytes past the tensor when it is the last channel of the last image
+        // (found as a memory fault once the allocation behind such a tensor happened to be unmapped)
+        const uint32_t jc = jin ? (uint32_t)j : (uint32_t)g.ncols - (VB ? 4u : 1u);
         const uint32_t n = fd_div(jc, g.fdP);
         const uint32_t p = jc - n * g.P;
         const uint32_t ho = fd_div(p, g.fdWo), wo = p - ho * g.Wo;
