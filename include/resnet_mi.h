@@ -395,6 +395,11 @@ int mi_op_conv_wgrad_bf16(const void *x_bf16, const void *dy_bf16, float *dw_kcr
 int mi_op_conv_dgrad_bn_bwd_bf16(const float *w_kcrs, const void *dy, const void *addend, void *gated, int N, int C, int H, int K, int k,
                                  int stride, const void *bn_x, const void *mask, const float *gamma, const float *beta, const float *means,
                                  const float *vars, float eps, void *bn_dx, float *dgamma, float *dbeta);
+/* the same chain in fp32 storage: dgrads with stride 1 on the MFMA implicit-GEMM route do the reduction in their epilogue.  Image tensors
+ * fp32.  Returns < 0 on error, else the number of partial rows the dgrad left (0 = separate pass). */
+int mi_op_conv_dgrad_bn_bwd_f32(const float *w_kcrs, const float *dy, const float *addend, float *gated, int N, int C, int H, int K, int k,
+                                int stride, const float *bn_x, const float *mask, const float *gamma, const float *beta, const float *means,
+                                const float *vars, float eps, float *bn_dx, float *dgamma, float *dbeta);
 /* the stem convolution of the bf16 storage mode (7x7 stride 2, 3 -> 64 filters, H a multiple of 32; doConvolution /
  * convolutionDerivWeights, resnet.cu:109-156, 227-281): fp32 tensors in and out, image and weights rounded to bf16 inside,
  * fp32 accumulation on the bf16 matrix cores.  -2: shape not covered (the trainer then keeps the fp32 stem). */

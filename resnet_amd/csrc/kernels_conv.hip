@@ -663,7 +663,7 @@ size_t mi_igemm_tail_floats(void);
 int mi_igemm_fwd(hipStream_t st, mid_workspace *ws, const float *x, const float *w, float *y, int N, int C, int H, int K, int k,
                  int stride, mid_bn_parts *parts);
 int mi_igemm_dgrad(hipStream_t st, mid_workspace *ws, const float *w, const float *dy, float *dx, const float *addend, int N,
-                   int C, int H, int K, int k, int stride);
+                   int C, int H, int K, int k, int stride, mid_bn_bwd_parts *fz = nullptr);
 int mi_igemm_wgrad(hipStream_t st, mid_workspace *ws, const float *x, const float *dy, float *dw, int N, int C, int H, int K, int k,
                    int stride);
 
@@ -707,6 +707,15 @@ int mid_conv_fwd_stats(mid_stream s, mid_workspace *ws, const float *x, const fl
     return launch_dconv(st, x, ws->wt, y, nullptr, a, k, k);
 }
 
+/* dgrad + the reduction pass of the batch-norm backward its output feeds, where the launch takes the fp32 implicit-GEMM route with
+ * stride 1: fz->nparts > 0 on return says the epilogue did it (dx then holds the gated gradient); 0 = plain dgrad was run */
+int mid_conv_dgrad_bn_f32(mid_stream s, mid_workspace *ws, const float *w, const float *dy, float *dx, const float *addend,
+                          int N, int C, int H, int K, int k, int stride, mid_bn_bwd_parts *fz) {
+    if (fz) fz->nparts = 0;
+    if (fz && stride == 1 && mi_igemm_supported(IGOP_DGRAD, N, C, H, K, k, stride))
+        return mi_igemm_dgrad((hipStream_t)s, ws, w, dy, dx, addend, N, C, H, K, k, stride, fz);
+    return mid_conv_dgrad(s, ws, w, dy, dx, addend, N, C, H, K, k, stride);
+}
 int mid_conv_dgrad(mid_stream s, mid_workspace *ws, const float *w, const float *dy, float *dx, const float *addend,
                    int N, int C, int H, int K, int k, int stride) {
     hipStream_t st = (hipStream_t)s;

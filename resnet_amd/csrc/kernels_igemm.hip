@@ -65,7 +65,24 @@ struct IgArgs {
     // the columns of a (tile, 128/PPT-column group); PPT = 2 for 128-row tiles, 4 for 64-row tiles); nullptr = off
     float *bn_part;
     int bn_np;
+    // dgrad (stride 1) that also does the REDUCTION pass of the batch-norm backward its output feeds (as the bf16 kernel does): the
+    // stored gradient is gated by bnb_mask > 0, and per (64-row wave tile, channel) the sums of g and g (x - mean) over the wave's
+    // columns go to bnb_part (two planes [bnb_np][C]); nullptr = off
+    const float *bnb_x, *bnb_mask, *bnb_mean;
+    float *bnb_part;
+    int bnb_np;
 };
+
+// sum over the 32 lanes of each half of a wave (lanes 0-31 / 32-63), on the vector ALU alone (DPP: no LDS crossbar traffic).  The
+// total of a half ends up in its lanes 16..31 (row_bcast15 hands a row's last lane to the next row).
+__device__ __forceinline__ float ig_half_sum32(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)); // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)); // row_mirror: every lane = its row's 16
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, true)); // row_bcast15 into rows 1 and 3
+    return v;
+}
 
 // (count, mean, M2) of one value per lane over the first nv lanes of each 32-lane half: shifted sums about the half's
 // first value (no cancellation), butterfly over the half.  Result valid in every lane of the half.
@@ -438,6 +455,64 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
 #pragma unroll
                 for (int r = 0; r < 16; r++)
                     tb[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 128 + wn * WNC + j * 32 + (lane & 31)] = acc[i][j][r];
+        return;
+    }
+    if (MODE == IG_DGRAD && S == 1 && g.bnb_part) {
+        // dgrad + the reduction pass of the batch norm backward that consumes it: g = (mask > 0 ? acc (+ addend) : 0) is what gets
+        // stored, and the sums of g and g (x - mean) over this wave's WNC columns go out per channel (row).  A half-wave holds 32
+        // columns of ONE row per accumulator register, so a row's sum is a 32-lane DPP reduction; the TN column blocks are
+        // added in the lane first.  Columns past the end contribute zero and store nothing.
+        constexpr int PPT = 4 / WMW;
+        size_t coffj[TN];
+        bool cokj[TN];
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int col = n0 + wn * WNC + j * 32 + (lane & 31);
+            cokj[j] = col < g.ncols;
+            const uint32_t jc = cokj[j] ? (uint32_t)col : 0u;
+            const uint32_t n = fd_div(jc, g.fdP);
+            coffj[j] = (size_t)n * g.C * g.HW + (jc - n * g.P);
+        }
+        const size_t rstride = (size_t)g.HW;
+        const size_t pplane = (size_t)g.bnb_np * g.C;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            float s1[16], s2[16], mn[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                s1[r] = 0.f; s2[r] = 0.f;
+                mn[r] = g.bnb_mean[m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                float ad[16], xv[16], mv[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) { // all reads first: one latency
+                    const size_t o = coffj[j] + (size_t)(m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * rstride;
+                    ad[r] = (addend && cokj[j]) ? addend[o] : 0.f;
+                    xv[r] = cokj[j] ? g.bnb_x[o] : 0.f;
+                    mv[r] = cokj[j] ? g.bnb_mask[o] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const float gv = mv[r] > 0.f ? acc[i][j][r] + ad[r] : 0.f;
+                    if (cokj[j]) Out[coffj[j] + (size_t)row * rstride] = gv;
+                    s1[r] += gv;
+                    s2[r] = fmaf(gv, xv[r] - mn[r], s2[r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float t1 = ig_half_sum32(s1[r]), t2 = ig_half_sum32(s2[r]);
+                if ((lane & 31) == 31) {
+                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const size_t po = (size_t)(ct * PPT + wn) * g.C + row;
+                    g.bnb_part[po] = t1;
+                    g.bnb_part[pplane + po] = t2;
+                }
+            }
+        }
         return;
     }
 #pragma unroll
@@ -872,8 +947,11 @@ int mi_igemm_fwd(hipStream_t st, mid_workspace *ws, const float *x, const float 
     return 0;
 }
 
+// fz (optional): the reduction pass of the batch-norm backward that consumes dx, fused into this kernel's epilogue (stride 1);
+// fz->nparts > 0 on return says it did (dx then holds the GATED gradient)
 int mi_igemm_dgrad(hipStream_t st, mid_workspace *ws, const float *w, const float *dy, float *dx, const float *addend, int N,
-                   int C, int H, int K, int k, int stride) {
+                   int C, int H, int K, int k, int stride, mid_bn_bwd_parts *fz) {
+    if (fz) fz->nparts = 0;
     const int T = k * k;
     const float *A = w; // 1x1: the KC tensor is already [k][c]
     if (k == 3) {
@@ -892,10 +970,20 @@ int mi_igemm_dgrad(hipStream_t st, mid_workspace *ws, const float *w, const floa
     g.tiles = g.mtiles * mi_cdiv(g.ncols, 128);
     g.fdM = make_fastdiv(g.mtiles);
     g.cpt = K / IG_BK; g.fdCpt = make_fastdiv(g.cpt);
-    // (stride 2: the four parity classes of unequal length already fill the rounds; no slicing)
-    igemm_tail_plan(g, T * g.cpt, stride == 1 && ws && ws->wt_floats >= (size_t)T * C * K + IG_TAIL_FLOATS ? ws->wt + (size_t)T * C * K : nullptr, bm);
+    bool fused = false;
+    if (fz && fz->buf && stride == 1) {
+        const int np = mi_cdiv(g.ncols, 128) * (bm == 128 ? 2 : 4);
+        if (fz->floats >= (size_t)2 * np * C) {
+            g.bnb_x = (const float *)fz->x; g.bnb_mask = (const float *)fz->mask; g.bnb_mean = fz->means;
+            g.bnb_part = fz->buf; g.bnb_np = np; fz->nparts = np;
+            fused = true;
+        }
+    }
+    // (stride 2: the four parity classes of unequal length already fill the rounds; no slicing.  With the BN' reduction in the
+    // epilogue every tile is launched whole: the slices' second stage does not carry it)
+    igemm_tail_plan(g, T * g.cpt, !fused && stride == 1 && ws && ws->wt_floats >= (size_t)T * C * K + IG_TAIL_FLOATS ? ws->wt + (size_t)T * C * K : nullptr, bm);
     mi_prof_begin(st, igemm_fam(k), 2.0 * T * (double)g.ncols * C * K,
-                  4.0 * ((double)g.ncols * K + (double)T * C * K + (double)N * C * g.HW * (addend ? 2 : 1)));
+                  4.0 * ((double)g.ncols * K + (double)T * C * K + (double)N * C * g.HW * ((addend ? 2 : 1) + (fused ? 2 : 0))));
     int rc = igemm_launch<IG_DGRAD>(st, dim3(g.full + (g.tiles - g.full) * g.tsplit, stride == 2 ? 4 : 1), A, dy, dx, addend, g, k, stride, bm);
     if (!rc && g.tsplit > 1) {
         if (bm == 128) hipLaunchKernelGGL((igemm_tail_reduce_kernel<IG_DGRAD, 128>), dim3(g.tiles - g.full, 8), dim3(256), 0, st, dx, addend, g);

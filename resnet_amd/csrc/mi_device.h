@@ -126,6 +126,9 @@ typedef struct {
 } mid_bn_bwd_parts;
 int mid_conv_dgrad_bn_bf16(mid_stream s, mid_workspace *ws, const float *w, const void *dy, void *dx, const void *addend, int N, int C,
                            int H, int K, int k, int stride, mid_bn_bwd_parts *fz);
+/* the same for fp32 storage (kernels_igemm.hip): stride-1 layers on the implicit-GEMM route; otherwise a plain dgrad, nparts = 0 */
+int mid_conv_dgrad_bn_f32(mid_stream s, mid_workspace *ws, const float *w, const float *dy, float *dx, const float *addend, int N, int C,
+                          int H, int K, int k, int stride, mid_bn_bwd_parts *fz);
 int mid_bn_bwd_parts_t(mid_stream s, float *stats_ws, const mid_bn_bwd_parts *parts, const void *x, int x_dt, const float *gamma,
                        const float *beta, const float *means, const float *vars, const void *dy_gated, int a_dt, void *dx, float *dgamma,
                        float *dbeta, int N, int C, int P, float eps);

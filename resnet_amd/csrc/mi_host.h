@@ -72,7 +72,7 @@ typedef struct MiCtx {
     /* bf16: the reduction pass of a unit's BN' done by the dgrad that produces its dy (mid_conv_dgrad_bn_bf16).  backwards_pass
      * fills fz_req before the unit whose dgrad should do it; the unit's dgrad moves it to fz_done (nparts > 0) for the next unit_bwd */
     mid_bn_bwd_parts fz_req, fz_done;
-    int fz_req_valid, fz_ready, fz_enable;
+    int fz_req_valid, fz_ready, fz_enable, fz_f32; /* fz_f32: the fp32 dgrads do it too (RESNET_MI_F32_BNFUSE_BWD, default on) */
     float *stem_dx;              /* bf16 mode: the stem convolution's output gradient stays fp32 */
     void *stem_xp; size_t stem_xp_bytes;           /* bf16 mode: the batch as zero-padded bf16 parity planes (kernels_stem_bf16.hip) */
     float *stem_scratch; size_t stem_scratch_floats; /*            its wave partials + re-laid weights; NULL = the fp32 stem kernels */

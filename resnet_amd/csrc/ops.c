@@ -170,6 +170,36 @@ int mi_op_conv_dgrad_bn_bwd_bf16(const float *w, const void *dy, const void *add
     ws_free(&ws);
     return rc < 0 ? rc : fz.nparts;
 }
+/* the same chain in fp32 storage (backwards_pass, fp32 trainer): the stride-1 layers on the implicit-GEMM route do the reduction pass of
+ * the batch-norm backward in the dgrad's epilogue */
+int mi_op_conv_dgrad_bn_bwd_f32(const float *w, const float *dy, const float *addend, float *gated, int N, int C, int H, int K, int k, int stride,
+                                const float *bn_x, const float *mask, const float *gamma, const float *beta, const float *means,
+                                const float *vars, float eps, float *bn_dx, float *dgamma, float *dbeta) {
+    mid_workspace ws;
+    if (ws_make(&ws, mid_conv_ws_wt_floats(C, K, k), 0)) return -3;
+    mid_bn_bwd_parts fz = {bn_x, mask, means, NULL, mid_bn_parts_floats(N, C, H), 0};
+    fz.buf = (float *)mid_malloc(fz.floats * sizeof(float));
+    float *bws = (float *)mid_malloc(mid_bn_ws_floats(C) * sizeof(float));
+    const size_t bytes = (size_t)N * C * H * H * 4;
+    if (addend) mid_memcpy_d2d(gated, addend, bytes, mi_global()->compute);
+    int rc = mid_conv_dgrad_bn_f32(mi_global()->compute, &ws, w, dy, gated, addend ? gated : NULL, N, C, H, K, k, stride, &fz);
+    if (!rc) {
+        if (fz.nparts > 0)
+            rc = mid_bn_bwd_parts_t(mi_global()->compute, bws, &fz, bn_x, MID_F32, gamma, beta, means, vars, gated, MID_F32, bn_dx, dgamma, dbeta, N, C, H * H, eps);
+        else { /* the unfused chain: BN' gates by the mask itself (mode 3 writes the gated gradient where the fused form leaves it) */
+            float *tmp = (float *)mid_malloc(bytes);
+            rc = mid_bn_bwd_t(mi_global()->compute, bws, bn_x, MID_F32, gamma, beta, means, vars, gated, mask, tmp, MID_F32, bn_dx, dgamma, dbeta, N, C, H * H, eps, 3);
+            if (!rc) mid_memcpy_d2d(gated, tmp, bytes, mi_global()->compute);
+            rc = finish(rc);
+            mid_free(tmp);
+        }
+    }
+    rc = finish(rc);
+    mid_free(bws);
+    mid_free(fz.buf);
+    ws_free(&ws);
+    return rc < 0 ? rc : fz.nparts;
+}
 /* the bf16-mode stem (7x7 stride 2, 3 -> 64): x, y, dy fp32 tensors; image and weights rounded to bf16 inside */
 int mi_op_stem_fwd_bf16(const float *x, const float *w, float *y, int N, int H) {
     if (!mid_stem_bf16_supported(3, H, 64, 7, 2)) return -2;

@@ -509,6 +509,13 @@ Train_ResNet *init_trainer(ResNet *model, Batch *cur_batch, int batch_size, floa
     c->world = 1; c->bucket_bytes = (size_t)32 << 20;
     c->dtype = MID_F32; c->policy = MI_STORE_FAST;
     c->fz_enable = !(getenv("RESNET_MI_BF16_BNFUSE_BWD") && atoi(getenv("RESNET_MI_BF16_BNFUSE_BWD")) == 0);
+    /* fp32 storage: which dgrads do it (bits: 1 expansion dgrad -> spatial BN', 2 spatial dgrad -> reduction BN', 4 reduction dgrad -> the
+     * expansion BN' of the identity block below); RESNET_MI_F32_BNFUSE_BWD overrides.  Measured at batch 256 (same box, ms/step):
+     * none 108.3-109.5, site 4 alone 108.3-108.9, site 1 alone 109.4-110.2, sites 1+2 111.6-112.8, all 111.7-112.2 -- the fp32 epilogue
+     * keeps lane = column, so the fused form reads x / mask / addend with 4-byte accesses (four times the memory instructions of the
+     * bf16 kernel's row-major drain) and pays for it wherever the separate reduction pass was only 2 tensors; site 4 replaces a
+     * 4-tensor pass and breaks even, so it is the default */
+    c->fz_f32 = mid_igemm_mode() >= 2 ? (getenv("RESNET_MI_F32_BNFUSE_BWD") ? atoi(getenv("RESNET_MI_F32_BNFUSE_BWD")) : 4) : 0;
     c->overlap_wgrad = getenv("RESNET_MI_OVERLAP") ? atoi(getenv("RESNET_MI_OVERLAP")) : 1;
     c->ev_bn_done = mid_event_create(); c->ev_wgrad_done = mid_event_create();
 
@@ -870,6 +877,9 @@ static void conv_dgrad_t(Train_ResNet *t, const float *w, const float *dy, float
     if (c->dtype == MID_BF16 && c->fz_req_valid) { /* ... and the reduction pass of the BN' its output feeds */
         ck(mid_conv_dgrad_bn_bf16(G.compute, &c->ws, w, dy, dx, addend, t->batch_size, C, H, K, k, stride, &c->fz_req), "convolution dgrad + BN' reduction (bf16)");
         if (c->fz_req.nparts > 0) { c->fz_done = c->fz_req; c->fz_ready = 1; }
+    } else if (c->fz_req_valid) { /* fp32 storage: the stride-1 layers on the implicit-GEMM route do the same */
+        ck(mid_conv_dgrad_bn_f32(G.compute, &c->ws, w, dy, dx, addend, t->batch_size, C, H, K, k, stride, &c->fz_req), "convolution dgrad + BN' reduction");
+        if (c->fz_req.nparts > 0) { c->fz_done = c->fz_req; c->fz_ready = 1; }
     } else if (c->dtype == MID_BF16) ck(mid_conv_dgrad_bf16(G.compute, &c->ws, w, dy, dx, addend, t->batch_size, C, H, K, k, stride), "convolution dgrad (bf16)");
     else ck(mid_conv_dgrad(G.compute, &c->ws, w, dy, dx, addend, t->batch_size, C, H, K, k, stride), "convolution dgrad");
     c->fz_req_valid = 0;
@@ -971,8 +981,10 @@ void backwards_pass(Train_ResNet *t) {
             if (b->projection) dk->transformed_residual = ring_take(c, &s_proj);
         }
         /* bf16 + FAST: a dgrad may do the reduction pass of the BN' its output feeds (and gate that output) */
-        const int fz = c->fz_enable && c->dtype == MID_BF16; /* (RECOMPUTE_BN: the gating tensors have just been re-derived when the dgrad runs) */
-#define FZ_REQ(x_, mask_, means_) do { if (fz) { c->fz_req.x = (x_); c->fz_req.mask = (mask_); c->fz_req.means = (means_); \
+        /* (RECOMPUTE_BN: the gating tensors have just been re-derived when the dgrad runs.)  fp32 storage: not with the FULL policy
+         * (its derivative mirror keeps the ungated gradients the dump tree names) */
+        const int fz = c->fz_enable && (c->dtype == MID_BF16 || (c->fz_f32 && c->policy != MI_STORE_FULL));
+#define FZ_REQ(site_, x_, mask_, means_) do { if (fz && (c->dtype == MID_BF16 || (c->fz_f32 & (site_)))) { c->fz_req.x = (x_); c->fz_req.mask = (mask_); c->fz_req.means = (means_); \
         c->fz_req.buf = c->bn_parts.buf; c->fz_req.floats = c->bn_parts.floats; c->fz_req.nparts = 0; c->fz_req_valid = 1; } } while (0)
         const int up_gated = c->fz_ready; /* the block above's reduction dgrad already gated `up` by this block's output and summed for the expansion BN' */
         if (b->projection) {
@@ -994,7 +1006,7 @@ void backwards_pass(Train_ResNet *t) {
         if (recompute) /* the expansion's input, re-derived: relu(BN(post_spatial)) (resnet_clean.cu:2753) */
             ck(mid_bn_apply_t(G.compute, k->post_spatial, c->dtype, b->norm_spatial->gamma, b->norm_spatial->beta, NULL, k->norm_post_spatial->means,
                               k->norm_post_spatial->vars, k->post_spatial_activated, c->dtype, N, b->reduced_depth, Ho * Ho, t->eps, 1), "BN recompute");
-        FZ_REQ(k->post_spatial, k->post_spatial_activated, k->norm_post_spatial->means); /* expansion dgrad -> spatial BN' */
+        FZ_REQ(1, k->post_spatial, k->post_spatial_activated, k->norm_post_spatial->means); /* expansion dgrad -> spatial BN' */
         unit_bwd(t, k->post_spatial_activated, b->depth_expansion, b->norm_expansion, k->norm_post_expanded,
                  db->norm_expansion, k->post_expanded, exp_dy, exp_mask, exp_mode, dk->output, dk->post_expanded, s_exp,
                  dk->post_spatial_activated, NULL, db->depth_expansion, b->reduced_depth, Ho, b->expanded_depth, 1, 1, 0);
@@ -1005,14 +1017,14 @@ void backwards_pass(Train_ResNet *t) {
                               k->norm_post_reduced->means, k->norm_post_reduced->vars, k->post_reduced_activated, c->dtype, N, b->reduced_depth,
                               H * H, t->eps, 1), "BN recompute");
         if (c->par) set_cur_par(c, c->par[i].spatial, c->par[i].spatial_bytes, &c->par[i].spatial_valid); else set_cur_par(c, NULL, 0, NULL);
-        FZ_REQ(k->post_reduced, k->post_reduced_activated, k->norm_post_reduced->means); /* spatial dgrad -> reduction BN' */
+        FZ_REQ(2, k->post_reduced, k->post_reduced_activated, k->norm_post_reduced->means); /* spatial dgrad -> reduction BN' */
         unit_bwd(t, k->post_reduced_activated, b->spatial, b->norm_spatial, k->norm_post_spatial, db->norm_spatial,
                  k->post_spatial, dk->post_spatial_activated, NULL, 1, NULL, dk->post_spatial, s_spa, dk->post_reduced_activated, NULL,
                  db->spatial, b->reduced_depth, H, b->reduced_depth, 3, b->stride, 0);
         if (ring) dk->post_reduced = ring_take(c, &s_red);
         if (i > 0 && !p->conv_blocks[i - 1]->projection) { /* reduction dgrad -> the expansion BN' of the identity block below */
             const Activation_ConvBlock *kb = a->activation_conv_blocks[i - 1];
-            FZ_REQ(kb->post_expanded, kb->output_activated, kb->norm_post_expanded->means);
+            FZ_REQ(4, kb->post_expanded, kb->output_activated, kb->norm_post_expanded->means);
         }
         unit_bwd(t, bin, b->depth_reduction, b->norm_depth_reduction, k->norm_post_reduced, db->norm_depth_reduction,
                  k->post_reduced, dk->post_reduced_activated, NULL, 1, NULL, dk->post_reduced, s_red, dbin, red_addend,

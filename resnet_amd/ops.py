@@ -248,6 +248,22 @@ class Ops:
             self._chk(rc, "conv_dgrad_bn_bwd_bf16")
         return self.get_t(gated, BF), self.get_t(bdx, BF), og.get(), ob.get(), rc > 0
 
+    def conv_dgrad_bn_bwd_f32(self, w, dy, H, stride, bn_x, mask, gamma, beta, means, vars_, eps, addend=None):
+        """fp32 twin of conv_dgrad_bn_bwd_bf16"""
+        N = dy.shape[0]
+        K, Cc, k, _ = w.shape
+        dw, ddy = self.dev(w), self.dev(dy)
+        dadd = self.dev(addend) if addend is not None else None
+        dxb, dmask = self.dev(bn_x), self.dev(mask)
+        dg, db, dm, dv = (self.dev(a) for a in (gamma, beta, means, vars_))
+        gated, bdx = self.dev(shape=(N, Cc, H, H)), self.dev(shape=(N, Cc, H, H))
+        og, ob = self.dev(shape=(Cc,)), self.dev(shape=(Cc,))
+        rc = self.L.mi_op_conv_dgrad_bn_bwd_f32(dw.ptr, ddy.ptr, dadd.ptr if dadd else None, gated.ptr, N, Cc, H, K, k, stride, dxb.ptr, dmask.ptr,
+                                                dg.ptr, db.ptr, dm.ptr, dv.ptr, eps, bdx.ptr, og.ptr, ob.ptr)
+        if rc < 0:
+            self._chk(rc, "conv_dgrad_bn_bwd_f32")
+        return gated.get(), bdx.get(), og.get(), ob.get(), rc > 0
+
     def stem_fwd_bf16(self, x, w, exact=False):
         """the matrix-core stem: operands rounded to bf16, or (exact) fp32 arithmetic"""
         N, _, H, _ = x.shape

@@ -566,7 +566,7 @@ def test_resnet50_bf16_every_block_and_both_bn_backward_routes(oracle):
         shared.forward(torch_ref.nhwc_to_nchw(im), lab)
         out15 = rel_l2(tr.activation("conv_blocks/15/output_activated"), shared.acts["b15_out"].detach().numpy())
         print("  damped residual branches, batch 8: last block output, HIP vs the rounding model with the product's gates: %.2e" % out15)
-        assert out15 <= 2e-2, out15
+        assert out15 <= 4e-2, out15  # (0.31 with gamma ~ 1 on the residual branches)
         return [g.reshape(-1).copy() for g in shared.backward()]
 
     gd, shared = run(8, 1, shared_gate_model)

@@ -341,3 +341,46 @@ def test_conv_shape_sweep(ops, oracle, shape):
     check_grad(nhwc(ops.conv_dgrad(w, nchw(dy), H, stride, dx_init=nchw(base))), oracle.conv_dgrad(w, dy, H, stride, dx_init=base),
                "dgrad+add %s" % (shape,))
     check_grad(ops.conv_wgrad(nchw(x), nchw(dy), k, stride), oracle.conv_wgrad(x, dy, k, stride), "wgrad %s" % (shape,))
+
+
+# (C, H, K, k, stride, N): dgrads as backwards_pass chains them with the batch-norm backward in front of them
+DGRAD_BN_SHAPES = [
+    (64, 56, 256, 1, 1, 2),      # expansion dgrad -> spatial BN'
+    (256, 56, 64, 1, 1, 2),      # reduction dgrad -> the expansion BN' of the identity block below (+ shortcut addend)
+    (128, 28, 128, 3, 1, 3),     # spatial dgrad -> reduction BN'
+    (512, 28, 128, 1, 1, 2),
+    (1024, 14, 256, 1, 1, 3),
+    (256, 14, 256, 3, 1, 3),
+    (2048, 7, 512, 1, 1, 5),     # P = 49: the scalar-staging variant of the kernel; 245 columns: ragged last tile
+    (512, 7, 512, 3, 1, 5),
+    (128, 56, 128, 3, 2, 2),     # stride-2 dgrad: not fused, the separate reduction pass runs
+    (64, 10, 64, 1, 1, 3),       # ragged: 300 columns
+    (256, 4, 128, 1, 1, 4),      # 64 columns: half a tile
+]
+
+
+@pytest.mark.parametrize("shape", DGRAD_BN_SHAPES, ids=["C%d_H%d_K%d_k%d_s%d_N%d" % s for s in DGRAD_BN_SHAPES])
+@pytest.mark.parametrize("with_addend", [0, 1])
+def test_dgrad_with_the_bn_backward_reduction_in_its_epilogue_f32(ops, oracle, shape, with_addend):
+    """prepreAndDoConvolutionDeriv + activationAndBatchNormDeriv chained (resnet.cu:1399-1429, 1455-1480): on the MFMA route a stride-1
+    dgrad gates its output by the sign of the activation, stores the gated gradient and leaves per-tile sums of g and g (x - mean);
+    the batch norm backward then only merges and applies.  Against the oracle's dgrad -> ReLU' -> BN' chain."""
+    C, H, K, k, stride, N = shape
+    eps = 1e-7
+    _, w, dy = _conv_data(*shape)
+    bn_x = (rand((N, H, H, C), 21, 1.5) + 0.3).astype(np.float32)   # the convolution output the batch norm normalised
+    gamma = (1 + 0.2 * rand((C,), 22)).astype(np.float32)
+    beta = (0.3 * rand((C,), 23)).astype(np.float32)
+    means, vars_, xhat, norm, act = oracle.bn_fwd(bn_x, gamma, beta, eps, 1)
+    addend = rand((N, H, H, C), 24) if with_addend else None
+    ref_d = oracle.conv_dgrad(w, dy, H, stride, dx_init=addend) if with_addend else oracle.conv_dgrad(w, dy, H, stride)
+    ref_g = np.where(act > 0, ref_d, 0).astype(np.float32)
+    rdx, rdg, rdb = oracle.bn_bwd(bn_x, gamma, eps, means, vars_, xhat, act, ref_g, 0)   # dy already gated
+    gated, bdx, dg, db, fused = ops.conv_dgrad_bn_bwd_f32(w, nchw(dy), H, stride, nchw(bn_x), nchw(act), gamma, beta, means, vars_, eps,
+                                                          addend=nchw(addend) if with_addend else None)
+    assert fused == (stride == 1), "which launches fuse"
+    check_grad(nhwc(gated), ref_g, "gated dgrad %s" % (shape,))
+    assert np.array_equal(nhwc(gated) == 0, ref_g == 0) or rel_l2(nhwc(gated), ref_g) < 1e-5  # the gates themselves
+    check_grad(db, rdb, "dbeta")
+    check_grad(dg, rdg, "dgamma")
+    check_grad(nhwc(bdx), rdx, "bn dx")
