@@ -463,6 +463,71 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
         // columns of ONE row per accumulator register, so a row's sum is a 32-lane DPP reduction; the TN column blocks are
         // added in the lane first.  Columns past the end contribute zero and store nothing.
         constexpr int PPT = 4 / WMW;
+        if ((g.P & 3) == 0) {
+            // Planes a multiple of 4 pixels (56^2, 28^2, 14^2): the tile goes through a wave-private LDS image [32 rows][WNC columns]
+            // (two halves in turn; the operand tiles are dead after the loop's last barrier) and is drained with lanes running ALONG a
+            // row -- 16 bytes per lane, CPR lanes per row: every access to x / mask / addend / dx is a run of whole 128-byte lines,
+            // and a row's sums are a DPP reduction over its CPR lanes.  (First form, kept below for the other planes: lane = column,
+            // 4-byte accesses -- four times the memory instructions; it cost more than the pass it replaced.)
+            constexpr int CPR = WNC / 4, RPI = 64 / CPR, PITCH = WNC + 4;
+            float *img = ig_smem + wave * (32 * PITCH);
+            const int c4 = (lane % CPR) * 4, r0 = lane / CPR;
+            const int col = n0 + wn * WNC + c4;
+            const bool cok = col < g.ncols;                     // (ncols % 4 == 0: the four columns are in or out together)
+            const uint32_t jc = cok ? (uint32_t)col : 0u;
+            const uint32_t nimg = fd_div(jc, g.fdP);
+            const size_t coff = (size_t)nimg * g.C * g.HW + (jc - nimg * g.P);
+            const size_t pplane = (size_t)g.bnb_np * g.C;
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        img[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * PITCH + j * 32 + (lane & 31)] = acc[i][j][r];
+                // (a wave reads only what it wrote: the LDS operations of a wave complete in order)
+#pragma unroll
+                for (int ps = 0; ps < 32 / RPI; ps++) {
+                    const int rl = ps * RPI + r0;
+                    const int row = m0 + wm * 64 + i * 32 + rl;
+                    const size_t o = coff + (size_t)row * g.HW;
+                    const pf4 z = {0.f, 0.f, 0.f, 0.f};
+                    pf4 v = *(const pf4 *)(img + rl * PITCH + c4);
+                    pf4 xv = z, mv = z;
+                    if (cok) {
+                        if (addend) v += *(const pf4 *)(addend + o);
+                        xv = *(const pf4 *)(g.bnb_x + o);
+                        mv = *(const pf4 *)(g.bnb_mask + o);
+                    }
+                    const float mean = g.bnb_mean[row];
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        v[e] = (cok && mv[e] > 0.f) ? v[e] : 0.f;
+                        s1 += v[e];
+                        s2 = fmaf(v[e], xv[e] - mean, s2);
+                    }
+                    if (cok) *(pf4 *)(Out + o) = v;
+                    // sum over the CPR lanes of the row (CPR = 16: one DPP row; 8: half of one)
+                    s1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0xB1, 0xF, 0xF, true));
+                    s2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s2), 0xB1, 0xF, 0xF, true));
+                    s1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0x4E, 0xF, 0xF, true));
+                    s2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s2), 0x4E, 0xF, 0xF, true));
+                    s1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0x141, 0xF, 0xF, true));
+                    s2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s2), 0x141, 0xF, 0xF, true));
+                    if (CPR == 16) {
+                        s1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0x140, 0xF, 0xF, true));
+                        s2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s2), 0x140, 0xF, 0xF, true));
+                    }
+                    if ((lane % CPR) == 0) {
+                        const size_t po = (size_t)(ct * PPT + wn) * g.C + row;
+                        g.bnb_part[po] = s1;
+                        g.bnb_part[pplane + po] = s2;
+                    }
+                }
+            }
+            return;
+        }
         size_t coffj[TN];
         bool cokj[TN];
 #pragma unroll
