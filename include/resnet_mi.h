@@ -395,6 +395,9 @@ int mi_op_conv_wgrad_bf16(const void *x_bf16, const void *dy_bf16, float *dw_kcr
 int mi_op_conv_dgrad_bn_bwd_bf16(const float *w_kcrs, const void *dy, const void *addend, void *gated, int N, int C, int H, int K, int k,
                                  int stride, const void *bn_x, const void *mask, const float *gamma, const float *beta, const float *means,
                                  const float *vars, float eps, void *bn_dx, float *dgamma, float *dbeta);
+/* 3x3 / stride-2 forward convolution on channel-last padded parity planes (x re-laid once, both operands by LDS-DMA; round 3).
+ * Same semantics and tensors as mi_op_conv_fwd_bf16 with k = 3, stride = 2; -2: shape not covered (C % 64, K % 128, output plane % 4) */
+int mi_op_conv_fwd_bf16_cl(const void *x_bf16, const float *w_kcrs, void *y_bf16, int N, int C, int H, int K);
 /* the same chain in fp32 storage: dgrads with stride 1 on the MFMA implicit-GEMM route do the reduction in their epilogue.  Image tensors
  * fp32.  Returns < 0 on error, else the number of partial rows the dgrad left (0 = separate pass). */
 int mi_op_conv_dgrad_bn_bwd_f32(const float *w_kcrs, const float *dy, const float *addend, float *gated, int N, int C, int H, int K, int k,

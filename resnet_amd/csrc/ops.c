@@ -315,3 +315,20 @@ int mi_debug_bn_merge(int R, int C, float *means, float *vars, float *dgamma, fl
     mid_free(tmp);
     return rc;
 }
+
+/* the 3x3 / stride-2 forward convolution of the bf16 path on channel-last padded parity planes (kernels_cl_bf16.hip): x re-laid, weights
+ * re-laid, then the LDS-DMA kernel.  -2: shape not covered (C % 64, K % 128, output plane % 4). */
+int mi_op_conv_fwd_bf16_cl(const void *x, const float *w, void *y, int N, int C, int H, int K) {
+    if (!mid_cl_fwd_supported(N, C, H, K)) return -2;
+    mid_stream st = mi_global()->compute;
+    const size_t xb = mid_cl_xp_bytes(N, C, H);
+    void *xp = mid_malloc(xb), *at = mid_malloc((size_t)9 * C * K * 2);
+    if (!xp || !at) { mid_free(xp); mid_free(at); return -3; }
+    mid_memset(xp, 0, xb, st);
+    int rc = mid_bf16_prelayout_fwd(st, w, at, K, C, 3);
+    if (!rc) rc = mid_cl_s2d(st, x, xp, N, C, H);
+    if (!rc) rc = mid_cl_fwd(st, xp, at, y, N, C, H, K, NULL);
+    rc = finish(rc);
+    mid_free(xp); mid_free(at);
+    return rc;
+}

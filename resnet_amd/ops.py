@@ -204,6 +204,16 @@ class Ops:
         self._chk(self.L.mi_op_conv_fwd_bf16(dx.ptr, dw.ptr, dy.ptr, N, Cc, H, K, k, stride), "conv_fwd_bf16")
         return self.get_t(dy, BF)
 
+    def conv_fwd_bf16_cl(self, x, w):
+        """3x3 stride-2 forward on channel-last padded parity planes (kernels_cl_bf16.hip)"""
+        N, Cc, H, _ = x.shape
+        K = w.shape[0]
+        BF = B.MI_DTYPE_BF16
+        dx, dw = self.dev_t(x, BF), self.dev(w)
+        dy = self.new_t((N, K, H // 2, H // 2), BF)
+        self._chk(self.L.mi_op_conv_fwd_bf16_cl(dx.ptr, dw.ptr, dy.ptr, N, Cc, H, K), "conv_fwd_bf16_cl")
+        return self.get_t(dy, BF)
+
     def conv_dgrad_bf16(self, w, dy, H, stride, dx_init=None):
         K, Cc, k, _ = w.shape
         N = dy.shape[0]

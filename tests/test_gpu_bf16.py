@@ -582,3 +582,32 @@ def test_resnet50_bf16_every_block_and_both_bn_backward_routes(oracle):
     print("  gradients, BN' reductions in the dgrad epilogues vs as passes of their own (batch 8): worst rel-L2 %.2e (location %d), median %.2e"
           % (max(errs), int(np.argmax(errs)), float(np.median(errs))))
     assert max(errs) <= R50_BF16_FUSED_VS_NOT, max(errs)
+
+
+# (C, H, K, N): 3x3 stride-2 layers for the channel-last kernel (C % 64, K % 128, output plane % 4)
+CL_SHAPES = [(128, 56, 128, 2), (256, 56, 512, 1), (256, 28, 256, 3), (512, 28, 1024, 3), (64, 16, 128, 5), (128, 8, 128, 4), (128, 8, 256, 3), (64, 4, 128, 7)]
+
+
+@pytest.mark.parametrize("shape", CL_SHAPES, ids=["C%d_H%d_K%d_N%d" % s for s in CL_SHAPES])
+@pytest.mark.parametrize("mb", ["auto", "2", "4"])
+def test_conv_fwd_bf16_channel_last(ops, oracle, shape, mb):
+    """kernels_cl_bf16.hip: x re-laid once as zero-padded channel-last parity planes, both operands by LDS-DMA; both wave-tile shapes
+    (RESNET_MI_CL_MB is read once per process, so the forced ones run in a child process).  Same oracle, same band as the NCHW kernel."""
+    C, H, K, N = shape
+    if mb != "auto":
+        import subprocess
+        import sys
+        code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_bf16 as t, conftest; "
+                "from resnet_amd.ops import Ops; from oracle.oracle_py import Oracle; "
+                "t.test_conv_fwd_bf16_channel_last(Ops(), Oracle('f32'), %r, 'auto')")
+        here = os.path.dirname(os.path.abspath(__file__))
+        r = subprocess.run([sys.executable, "-c", code % (os.path.dirname(here), here, shape)], env=dict(os.environ, RESNET_MI_CL_MB=mb),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        return
+    x = bf16_round(rand((N, H, H, C), 7))
+    w = bf16_round(rand((K, C, 3, 3), 8, scale=(2.0 / (9 * (C + K))) ** 0.5))
+    ref = oracle.conv_fwd(x, w, 2)
+    got = ops.conv_fwd_bf16_cl(nchw(x), w)
+    check_bf(nhwc(got), ref, "channel-last conv fwd %s" % (shape,))
+    assert np.array_equal(got, ops.conv_fwd_bf16(nchw(x), w, 2)) or rel_l2(got, ops.conv_fwd_bf16(nchw(x), w, 2)) < 2e-3
