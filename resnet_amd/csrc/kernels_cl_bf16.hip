@@ -30,12 +30,19 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16;
 
 struct ClArgs {
-    int N, C, K, Ho, Wo, Hp, Wp, P; // Hp = Ho + 1, Wp = Wo + 1, P = Ho * Wo
-    int ncols, mtiles, tiles;
-    FastDiv fdP, fdWo, fdM;
-    float *bn_part;                 // statistics partials, three planes [bn_np][K] (count, mean, M2), or nullptr
+    int Cin, M;                     // reduction channels per tap, output channels (rows of the product)
+    int GH, GW, P, ncols;           // output grid per image, P = GH * GW, ncols = N * P
+    int img_rows, Wp;               // padded input: rows per image (all planes), padded row length; pixel (n, y, x) of the grid reads
+                                    // the Cin channels at ((n img_rows + y) Wp + x) Cin, shifted by a per-tap constant
+    int ntaps;
+    uint32_t tap_delta[9];          // byte offset of tap t's operand row from the grid pixel's
+    int tap_w[9];                   // its weight tile: A = [tap_w][Cin / 64][M][64]
+    int mtiles, tiles;
+    FastDiv fdP, fdGW, fdM;
+    float *bn_part;                 // forward: statistics partials, three planes [bn_np][M] (count, mean, M2), or nullptr
     int bn_np;
-    int vw;                         // pixels per output store: 8 or 4 (P % vw == 0)
+    int vw;                         // pixels per output store: 8 / 4 (P % vw == 0), or 1 (any plane: 2-byte stores)
+    const u16 *addend;              // dgrad: shortcut gradient added before the one rounding to bf16 (same shape as the output), or nullptr
 };
 
 __device__ __forceinline__ uint32_t cl_pack2(float a, float b) {
@@ -43,47 +50,56 @@ __device__ __forceinline__ uint32_t cl_pack2(float a, float b) {
     bf16x2 r = __builtin_convertvector(v, bf16x2);
     return *(uint32_t *)&r;
 }
+__device__ __forceinline__ float cl_bf2f(u16 v) { return __uint_as_float((uint32_t)v << 16); }
 // 16-byte chunk `ch` of row `row` of a [rows][128 bytes] LDS image sits at chunk ch ^ key(row): rows r and r + 1 share a 256-byte bank
 // row, so the key changes every second row -- the 16 lanes of a ds_read_b128 group (16 consecutive rows, one chunk) then cover all 16
 // slots of the two-row bank period
 __device__ __forceinline__ int cl_key(int row) { return (row >> 1) & 7; }
 
-// x [N][C][H][W] bf16 -> Xp (see the header); interior only: the halo row / column are zeroed once, when the buffer is made.
-// block = (image, output row a - 1, 64-channel chunk): two input rows of 64 channels through LDS, out as 128-byte channel runs.
+// x [N][C][H][W] bf16 -> channel-last, zero-padded (interior only: the halo is zeroed once, when the buffer is made).
+//   PAR = 0: one plane   Xc[n][y + yoff][x + xoff][c], Hp x Wp  (3x3 stride 1: yoff = xoff = 1, Hp = H + 2; dY of a stride-2 dgrad:
+//            yoff = xoff = 0, Hp = H + 1 -- its taps look down / right)
+//   PAR = 1: four parity planes  Xp[n][2 pr + pc][a][b][c], Hp = H/2 + 1:  x[n][c][2 (a - 1) + pr][2 (b - 1) + pc]  (3x3 stride 2)
+// block = (64-channel chunk, input row or row pair, image): rows through LDS, out as 128-byte channel runs
+template <int PAR>
 __global__ void __launch_bounds__(256)
-cl_s2d_kernel(const u16 *__restrict__ x, u16 *__restrict__ xp, int C, int H, int W, int Hp, int Wp) {
+cl_relayout_kernel(const u16 *__restrict__ x, u16 *__restrict__ xp, int C, int H, int W, int Hp, int Wp, int yoff, int xoff) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cl_smem[];
-    u16 *tile = (u16 *)cl_smem;                   // [pr][pc][b'][64 channels], pitch 64 + 8 elements
+    u16 *tile = (u16 *)cl_smem;                   // [row of the block][x][64 channels], pitch 72 elements
     constexpr int PT = 72;
-    const int Wo = W / 2;
-    const int c0 = blockIdx.x * 64, a1 = blockIdx.y, n = blockIdx.z; // a1 = a - 1
-    const int pairs = 2 * 64 * Wo;                // (pr, channel, b') 4-byte pairs
-    for (int e = threadIdx.x; e < pairs; e += 256) {
-        const int bq = e % Wo, t = e / Wo, cc = t & 63, pr = t >> 6;
-        const uint32_t v = *(const uint32_t *)(x + (((size_t)n * C + c0 + cc) * H + 2 * a1 + pr) * W + 2 * bq);
-        tile[((pr * 2 + 0) * Wo + bq) * PT + cc] = (u16)(v & 0xffffu);
-        tile[((pr * 2 + 1) * Wo + bq) * PT + cc] = (u16)(v >> 16);
+    const int c0 = blockIdx.x * 64, yb = blockIdx.y, n = blockIdx.z;
+    constexpr int RW = PAR ? 2 : 1;               // input rows per block
+    const int total = RW * 64 * W;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int xx = e % W, t = e / W, cc = t & 63, rr = t >> 6;
+        tile[(rr * W + xx) * PT + cc] = x[(((size_t)n * C + c0 + cc) * H + RW * yb + rr) * W + xx];
     }
     __syncthreads();
-    const int pieces = 4 * Wo * 8;                // (q, b', 16-byte piece of the 64 channels)
+    const int pieces = RW * W * 8;                // (row, x, 16-byte piece of the 64 channels)
     for (int e = threadIdx.x; e < pieces; e += 256) {
-        const int pc8 = e & 7, t = e >> 3, bq = t % Wo, q = t / Wo;
-        const u32x4 v = *(const u32x4 *)(tile + (q * Wo + bq) * PT + pc8 * 8);
-        *(u32x4 *)(xp + ((((size_t)n * 4 + q) * Hp + a1 + 1) * Wp + bq + 1) * C + c0 + pc8 * 8) = v;
+        const int pc8 = e & 7, t = e >> 3, xx = t % W, rr = t / W;
+        const u32x4 v = *(const u32x4 *)(tile + (rr * W + xx) * PT + pc8 * 8);
+        size_t o;
+        if (PAR) o = ((((size_t)n * 4 + 2 * rr + (xx & 1)) * Hp + yb + 1) * Wp + (xx >> 1) + 1) * C;
+        else o = (((size_t)n * Hp + yb + yoff) * Wp + xx + xoff) * C;
+        *(u32x4 *)(xp + o + c0 + pc8 * 8) = v;
     }
 }
 
-// MB: 32-row M blocks per wave (2: workgroup tile 128 x 128, wave tile 64 x 64; 4: 256 x 128, wave tile 128 x 64)
-template <int MB>
+// Out[m][col] = sum over taps t, channels c:  A[tap_w[t]][c][m] * In[pixel(col) + tap_delta[t]][c]      (NCHW output, bf16)
+// WM: waves along M.  2: workgroup tile 128 (M) x 128 (pixels), waves 2 x 2; 1: 64 x 256, waves 1 x 4 (64-channel layers).  Wave tile 64 x 64.
+// NBUF: operand buffers (2: the DMA of k-step i + 1 runs under the MFMAs of k-step i, one barrier per k-step; 1: half the LDS, two
+// barriers per k-step, the overlap comes from the other workgroups of the CU)
+template <int WM, int NBUF>
 __global__ void __launch_bounds__(256)
-cl_fwd_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Xp, u16 *__restrict__ Out, const ClArgs g) {
-    constexpr int BM = 64 * MB;                    // rows (output channels) per workgroup
-    constexpr int NAU = BM / 32;                   // 16-byte DMA pieces of the A tile per thread
-    constexpr int ABYTES = BM * 128, BBYTES = 128 * 128, BUF = ABYTES + BBYTES;
+cl_conv_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ In, u16 *__restrict__ Out, const ClArgs g) {
+    constexpr int BM = 64 * WM, BN = 256 / WM;     // 128 x 128 or 64 x 256
+    constexpr int NAU = BM / 32, NBU = BN / 32;    // 16-byte DMA pieces per thread and tile
+    constexpr int ABYTES = BM * 128, BBYTES = BN * 128, BUF = ABYTES + BBYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char cl_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = WM == 2 ? wave >> 1 : 0, wn = WM == 2 ? wave & 1 : wave;
 
     // ---- block -> tile (XCD-contiguous, M-tiles fastest: the blocks that share a pixel tile share an L2) ----
     uint32_t L = blockIdx.x;
@@ -92,11 +108,11 @@ cl_fwd_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Xp, u16 *__re
         if (L < per * 8) L = (L & 7) * per + (L >> 3);
     }
     const uint32_t ct = fd_div(L, g.fdM);
-    const int m0 = (int)(L - ct * g.mtiles) * BM, n0 = (int)ct * 128;
+    const int m0 = (int)(L - ct * g.mtiles) * BM, n0 = (int)ct * BN;
 
-    f32x16 acc[MB][2];
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < MB; i++)
+    for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -105,14 +121,14 @@ cl_fwd_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Xp, u16 *__re
     // ---- DMA state: piece p = tid + 256 u of a tile lands at LDS byte 16 p (lane-linear), i.e. row p >> 3, chunk p & 7; it is
     // loaded from chunk (p & 7) ^ key(row) of that row's 128 source bytes ----
     const int prow = tid >> 3, pchunk = tid & 7;
-    uint32_t boff[4];                              // byte offset of the pixel row's channel 0 in Xp (tap 0, 0 not yet added)
+    uint32_t boff[NBU];                            // byte offset of the pixel row's channel 0 (no tap shift yet)
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < NBU; u++) {
         const int row = prow + 32 * u;
         const uint32_t j = (uint32_t)min(n0 + row, g.ncols - 1);   // columns past the end: a pixel that exists (never stored)
         const uint32_t n = fd_div(j, g.fdP), p = j - n * g.P;
-        const uint32_t oh = fd_div(p, g.fdWo), ow = p - oh * g.Wo;
-        boff[u] = (((n * 4u) * g.Hp + oh) * g.Wp + ow) * (uint32_t)g.C * 2u + (uint32_t)((pchunk ^ cl_key(row)) * 16);
+        const uint32_t y = fd_div(p, g.fdGW), xx = p - y * g.GW;
+        boff[u] = ((n * (uint32_t)g.img_rows + y) * g.Wp + xx) * (uint32_t)g.Cin * 2u + (uint32_t)((pchunk ^ cl_key(row)) * 16);
     }
     uint32_t aoff[NAU];
 #pragma unroll
@@ -120,22 +136,19 @@ cl_fwd_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Xp, u16 *__re
         const int row = prow + 32 * u;
         aoff[u] = (uint32_t)(row * 128 + ((pchunk ^ cl_key(row)) * 16));
     }
-    const int cpt = g.C / 64;                      // k-steps per tap
-    const int ntiles = 9 * cpt;
+    const int cpt = g.Cin / 64;                    // k-steps per tap
+    const int ntiles = g.ntaps * cpt;
     int ld_t = 0, ld_c = 0;
     auto issue = [&](const int buf) {
-        const int r = (ld_t * 11) >> 5, s = ld_t - 3 * r;
-        const int q = 2 * ((r + 1) & 1) + ((s + 1) & 1);
-        const uint32_t d = (uint32_t)(((q * g.Hp + (r > 0)) * g.Wp + (s > 0)) * g.C + ld_c * 64) * 2u;
-        const unsigned char *fa = (const unsigned char *)(Aop + ((size_t)(ld_t * cpt + ld_c) * g.K + m0) * 64);
-        const unsigned char *fb = (const unsigned char *)Xp + d;
+        const unsigned char *fa = (const unsigned char *)(Aop + ((size_t)(g.tap_w[ld_t] * cpt + ld_c) * g.M + m0) * 64);
+        const unsigned char *fb = (const unsigned char *)In + g.tap_delta[ld_t] + (uint32_t)(ld_c * 128);
         unsigned char *la = cl_smem + buf * BUF + wave * 1024, *lb = cl_smem + buf * BUF + ABYTES + wave * 1024;
 #pragma unroll
         for (int u = 0; u < NAU; u++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(fa + aoff[u]),
                                              (__attribute__((address_space(3))) void *)(la + u * 4096), 16, 0, 0);
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+        for (int u = 0; u < NBU; u++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(fb + boff[u]),
                                              (__attribute__((address_space(3))) void *)(lb + u * 4096), 16, 0, 0);
         if (++ld_c == cpt) { ld_c = 0; ld_t++; }
@@ -145,10 +158,10 @@ cl_fwd_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Xp, u16 *__re
         const unsigned char *as = cl_smem + buf * BUF, *bs = as + ABYTES;
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-            bf16x8 av[MB], bv[2];
+            bf16x8 av[2], bv[2];
 #pragma unroll
-            for (int i = 0; i < MB; i++) {
-                const int row = wm * (32 * MB) + i * 32 + fr;
+            for (int i = 0; i < 2; i++) {
+                const int row = wm * 64 + i * 32 + fr;
                 av[i] = *(const bf16x8 *)(as + row * 128 + (((2 * s + fk) ^ cl_key(row)) * 16));
             }
 #pragma unroll
@@ -157,157 +170,264 @@ cl_fwd_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ Xp, u16 *__re
                 bv[j] = *(const bf16x8 *)(bs + row * 128 + (((2 * s + fk) ^ cl_key(row)) * 16));
             }
 #pragma unroll
-            for (int i = 0; i < MB; i++)
+            for (int i = 0; i < 2; i++)
 #pragma unroll
                 for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[j], av[i], acc[i][j], 0, 0, 0);
         }
     };
 
-    issue(0);
-    for (int it = 0; it < ntiles; it++) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this thread's pieces of tile `it` have landed ...
-        __syncthreads();   // ... and so have everyone's; everyone is done with the other buffer
-        if (it + 1 < ntiles) issue((it + 1) & 1);
-        compute(it & 1);
+    if constexpr (NBUF == 2) {
+        issue(0);
+        for (int it = 0; it < ntiles; it++) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this thread's pieces of tile `it` have landed ...
+            __syncthreads();   // ... and so have everyone's; everyone is done with the other buffer
+            if (it + 1 < ntiles) issue((it + 1) & 1);
+            compute(it & 1);
+        }
+    } else {
+        for (int it = 0; it < ntiles; it++) {
+            issue(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute(0);
+            __syncthreads();
+        }
     }
     __syncthreads();       // the epilogue re-uses the operand buffers
 
     // ---- epilogue: accumulator (i, j): rows = the 32 pixels of column block j, row (r & 3) + 8 (r >> 2) + 4 (lane >> 5);
-    // column = channel m0 + wm 32 MB + i 32 + (lane & 31).  A quad r = 4 q .. 4 q + 3 is 4 consecutive pixels of one image (P % 4 == 0) ----
+    // column = channel m0 + wm 64 + i 32 + (lane & 31) ----
     const int l31 = lane & 31, hh = lane >> 5;
-    uint32_t okm = 0;
-    int cnt = 0;
+    const int colw = n0 + wn * 64;                 // the wave's first column
+    if (g.bn_part) { // lane-local statistics of the wave's 64 channels x 64 pixels (a lane holds 32 pixels of ONE channel per i)
+        int cnt = 0;
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+        for (int j = 0; j < 2; j++)
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int col = n0 + wn * 64 + j * 32 + 8 * q + 4 * hh;
-            if (col < g.ncols) { okm |= 1u << (j * 4 + q); cnt += 4; }
-        }
-    if (g.bn_part) { // lane-local statistics of the wave's 32 MB channels x 64 pixels (a lane holds 32 pixels of ONE channel per i)
+            for (int q = 0; q < 4; q++) cnt += max(0, min(4, g.ncols - (colw + j * 32 + 8 * q + 4 * hh)));
 #pragma unroll
-        for (int i = 0; i < MB; i++) {
-            const int m = m0 + wm * (32 * MB) + i * 32 + l31;
+        for (int i = 0; i < 2; i++) {
+            const int m = m0 + wm * 64 + i * 32 + l31;
             const float s0 = __shfl(acc[i][0][0], l31, 64); // the wave's first pixel (a real one if any is)
             float sd = 0.f, sq = 0.f;
 #pragma unroll
             for (int j = 0; j < 2; j++)
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const bool ok = (okm >> (j * 4 + q)) & 1u;
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const float dlt = ok ? acc[i][j][4 * q + e] - s0 : 0.f;
-                        sd += dlt;
-                        sq = fmaf(dlt, dlt, sq);
-                    }
+                for (int r = 0; r < 16; r++) {
+                    const int col = colw + j * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);
+                    const float dlt = col < g.ncols ? acc[i][j][r] - s0 : 0.f;
+                    sd += dlt;
+                    sq = fmaf(dlt, dlt, sq);
                 }
             sd += __shfl_xor(sd, 32, 64);
             sq += __shfl_xor(sq, 32, 64);
             const int nvw = cnt + __shfl_xor(cnt, 32, 64);
             if (hh == 0) {
+                constexpr int PPT = BN / 64;           // 64-column wave groups per tile
                 const float inv = nvw > 0 ? 1.0f / (float)nvw : 0.f;
-                const size_t plane = (size_t)g.bn_np * g.K;
-                const size_t o = (size_t)(ct * 2 + wn) * g.K + m;
+                const size_t plane = (size_t)g.bn_np * g.M;
+                const size_t o = (size_t)(ct * PPT + wn) * g.M + m;
                 g.bn_part[o] = (float)nvw;
                 g.bn_part[plane + o] = nvw > 0 ? s0 + sd * inv : 0.f;
                 g.bn_part[2 * plane + o] = fmaxf(sq - sd * sd * inv, 0.f);
             }
         }
     }
-    // stores through a wave-private LDS image [64 channels][64 pixels] (bf16, pitch 144 B), 64 channels at a time, read back with
-    // lanes running ALONG a channel row: a wave instruction writes whole 128-byte lines of y
-    constexpr int PITCH = 64 * 2 + 16;
-    unsigned char *img = cl_smem + wave * (64 * PITCH);
+    if (g.vw == 1) {
+        // planes that are not a multiple of 4 pixels (7 x 7): 2-byte stores straight from the accumulators, (image, pixel) per element
 #pragma unroll
-    for (int half = 0; half < MB / 2; half++) {
+        for (int j = 0; j < 2; j++)
 #pragma unroll
-        for (int ii = 0; ii < 2; ii++) {
-            const int i = half * 2 + ii;
+            for (int r = 0; r < 16; r++) {
+                const int col = colw + j * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);
+                if (col >= g.ncols) continue;
+                const uint32_t n = fd_div((uint32_t)col, g.fdP), pp = (uint32_t)col - n * g.P;
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const size_t o = ((size_t)n * g.M + m0 + wm * 64 + i * 32 + l31) * g.P + pp;
+                    float v = acc[i][j][r];
+                    if (g.addend) v += cl_bf2f(g.addend[o]);
+                    Out[o] = (u16)(cl_pack2(v, 0.f) & 0xffffu);
+                }
+            }
+        return;
+    }
+    // stores through a wave-private LDS image [64 channels][64 pixels] (fp32 when a shortcut gradient is added before the one
+    // rounding, else bf16), read back with lanes running ALONG a channel row: a wave instruction writes whole 128-byte lines
+    if (g.addend) {
+        constexpr int PITCH = 64 * 4 + 16;         // fp32 image, 32 channel rows at a time
+        unsigned char *img = cl_smem + wave * (32 * PITCH);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
 #pragma unroll
             for (int j = 0; j < 2; j++)
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    u32x2 v = {cl_pack2(acc[i][j][4 * q], acc[i][j][4 * q + 1]), cl_pack2(acc[i][j][4 * q + 2], acc[i][j][4 * q + 3])};
-                    *(u32x2 *)(img + (ii * 32 + l31) * PITCH + (j * 32 + 8 * q + 4 * hh) * 2) = v;
+                    typedef float pf4 __attribute__((ext_vector_type(4)));
+                    pf4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    *(pf4 *)(img + l31 * PITCH + (j * 32 + 8 * q + 4 * hh) * 4) = v;
                 }
-        }
-        auto drain = [&](auto cpx_tag) {
-            constexpr int CPX = decltype(cpx_tag)::value; // pixels per lane and store
-            constexpr int CPR = 64 / CPX, RPP = 64 / CPR;
-            const int c = lane % CPR, r0 = lane / CPR;
-            const int col = n0 + wn * 64 + c * CPX;
+            // 4 pixels per lane: 16 lanes along a row, 4 rows per instruction
+            const int c = lane & 15, r0 = lane >> 4;
+            const int col = colw + c * 4;
             const uint32_t cc = (uint32_t)min(col, g.ncols - 1);
             const uint32_t n = fd_div(cc, g.fdP), pp = cc - n * g.P;
             const bool ok = col < g.ncols;
-            const uint32_t obase = n * (uint32_t)(g.K * g.P) + pp;
+            const uint32_t obase = n * (uint32_t)(g.M * g.P) + pp;
 #pragma unroll
-            for (int ps = 0; ps < 64 / RPP; ps++) {
-                const int row = ps * RPP + r0;
-                const size_t o = (size_t)(obase + (uint32_t)(m0 + wm * (32 * MB) + half * 64 + row) * (uint32_t)g.P);
-                const unsigned char *sp = img + row * PITCH + c * CPX * 2;
-                if constexpr (CPX == 8) { const u32x4 v = *(const u32x4 *)sp; if (ok) *(u32x4 *)(Out + o) = v; }
-                else { const u32x2 v = *(const u32x2 *)sp; if (ok) *(u32x2 *)(Out + o) = v; }
+            for (int ps = 0; ps < 8; ps++) {
+                typedef float pf4 __attribute__((ext_vector_type(4)));
+                const int row = ps * 4 + r0;
+                const size_t o = (size_t)(obase + (uint32_t)(m0 + wm * 64 + i * 32 + row) * (uint32_t)g.P);
+                const pf4 v = *(const pf4 *)(img + row * PITCH + c * 16);
+                if (ok) {
+                    const u32x2 ad = *(const u32x2 *)(g.addend + o);
+                    u32x2 st = {cl_pack2(v[0] + __uint_as_float(ad[0] << 16), v[1] + __uint_as_float(ad[0] & 0xffff0000u)),
+                                cl_pack2(v[2] + __uint_as_float(ad[1] << 16), v[3] + __uint_as_float(ad[1] & 0xffff0000u))};
+                    *(u32x2 *)(Out + o) = st;
+                }
             }
-        };
-        if (g.vw == 8) drain(std::integral_constant<int, 8>{});
-        else drain(std::integral_constant<int, 4>{});
+        }
+        return;
     }
+    constexpr int PITCH = 64 * 2 + 16;
+    unsigned char *img = cl_smem + wave * (64 * PITCH);
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                u32x2 v = {cl_pack2(acc[i][j][4 * q], acc[i][j][4 * q + 1]), cl_pack2(acc[i][j][4 * q + 2], acc[i][j][4 * q + 3])};
+                *(u32x2 *)(img + (i * 32 + l31) * PITCH + (j * 32 + 8 * q + 4 * hh) * 2) = v;
+            }
+    auto drain = [&](auto cpx_tag) {
+        constexpr int CPX = decltype(cpx_tag)::value; // pixels per lane and store
+        constexpr int CPR = 64 / CPX, RPP = 64 / CPR;
+        const int c = lane % CPR, r0 = lane / CPR;
+        const int col = colw + c * CPX;
+        const uint32_t cc = (uint32_t)min(col, g.ncols - 1);
+        const uint32_t n = fd_div(cc, g.fdP), pp = cc - n * g.P;
+        const bool ok = col < g.ncols;
+        const uint32_t obase = n * (uint32_t)(g.M * g.P) + pp;
+#pragma unroll
+        for (int ps = 0; ps < 64 / RPP; ps++) {
+            const int row = ps * RPP + r0;
+            const size_t o = (size_t)(obase + (uint32_t)(m0 + wm * 64 + row) * (uint32_t)g.P);
+            const unsigned char *sp = img + row * PITCH + c * CPX * 2;
+            if constexpr (CPX == 8) { const u32x4 v = *(const u32x4 *)sp; if (ok) *(u32x4 *)(Out + o) = v; }
+            else { const u32x2 v = *(const u32x2 *)sp; if (ok) *(u32x2 *)(Out + o) = v; }
+        }
+    };
+    if (g.vw == 8) drain(std::integral_constant<int, 8>{});
+    else drain(std::integral_constant<int, 4>{});
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-extern "C" {
-/* shapes the channel-last forward covers: 3x3, stride 2, channels a multiple of 64, output planes a multiple of 4 pixels */
-int mid_cl_fwd_supported(int N, int C, int H, int K) {
-    if (H % 2 || H < 4 || H > 240) return 0;
-    const int Ho = H / 2, P = Ho * Ho;
-    if (C % 64 || K % 128 || P % 4) return 0;
-    if ((double)N * 4 * (Ho + 1) * (Ho + 1) * C * 2 >= 4294000000.0 || (double)N * K * P >= 2147480000.0) return 0; /* 32-bit byte offsets */
-    return 1;
-}
-size_t mid_cl_xp_bytes(int N, int C, int H) { return (size_t)N * 4 * (H / 2 + 1) * (H / 2 + 1) * C * 2; }
-/* x (bf16 NCHW) -> padded channel-last parity planes; the halo of xp must be zero (zero the buffer once when it is allocated) */
-int mid_cl_s2d(mid_stream s, const void *x, void *xp, int N, int C, int H) {
-    const int Ho = H / 2;
-    const size_t lds = (size_t)4 * Ho * 72 * 2;
-    hipLaunchKernelGGL(cl_s2d_kernel, dim3(C / 64, Ho, N), dim3(256), lds, (hipStream_t)s, (const u16 *)x, (u16 *)xp, C, H, H, Ho + 1, Ho + 1);
-    MI_LAUNCH_CHECK("cl_s2d_kernel");
-    return 0;
-}
-/* y (bf16 NCHW) = conv3x3 stride 2 of the planes xp with the weights a_tiles = bf16 k-step tiles [t][c/64][K][64] (the forward
- * layout of mid_conv_prelayout_all_bf16); parts (optional): BN statistics partials as mid_conv_fwd_bf16 leaves them */
-int mid_cl_fwd(mid_stream s, const void *xp, const void *a_tiles, void *y, int N, int C, int H, int K, mid_bn_parts *parts) {
-    hipStream_t st = (hipStream_t)s;
-    if (parts) parts->nparts = 0;
-    if (!mid_cl_fwd_supported(N, C, H, K)) { mi_record_error("mid_cl_fwd", "shape not covered"); return -2; }
-    ClArgs g = {};
-    g.N = N; g.C = C; g.K = K; g.Ho = H / 2; g.Wo = H / 2; g.Hp = g.Ho + 1; g.Wp = g.Wo + 1; g.P = g.Ho * g.Wo;
+static int cl_launch(hipStream_t st, const u16 *A, const u16 *In, u16 *Out, ClArgs &g, int N, double flops, double bytes) {
     g.ncols = N * g.P;
-    g.fdP = make_fastdiv(g.P); g.fdWo = make_fastdiv(g.Wo);
-    g.vw = g.P % 8 == 0 ? 8 : 4;
-    const int ctl = mi_cdiv(g.ncols, 128);
-    static int mb_force = -1;
-    if (mb_force < 0) { const char *e = getenv("RESNET_MI_CL_MB"); mb_force = e ? atoi(e) : 0; }
-    int mb = (K % 256 == 0 && (long)(K / 256) * ctl >= 512) ? 4 : 2; // 256-row tiles where they still fill the chip twice over
-    if (mb_force == 2 || (mb_force == 4 && K % 256 == 0)) mb = mb_force;
-    const int bm = 64 * mb;
-    g.mtiles = K / bm; g.tiles = g.mtiles * ctl; g.fdM = make_fastdiv(g.mtiles);
-    if (parts && parts->buf && parts->floats >= (size_t)3 * ctl * 2 * K) { g.bn_part = parts->buf; g.bn_np = ctl * 2; parts->nparts = ctl * 2; }
-    const size_t lds = (size_t)2 * (bm * 128 + 128 * 128);
-    mi_prof_begin(st, MI_FAM_PCONV, 2.0 * 9 * (double)N * g.P * C * K, 2.0 * ((double)N * C * H * H + (double)N * g.P * K) + 4.0 * 9 * C * K);
+    g.fdP = make_fastdiv(g.P); g.fdGW = make_fastdiv(g.GW);
+    g.vw = g.P % 8 == 0 ? 8 : g.P % 4 == 0 ? 4 : 1;
+    static int force = -1;
+    if (force < 0) { const char *e = getenv("RESNET_MI_CL_NBUF"); force = e ? atoi(e) : 0; }
+    const int nbuf = force == 1 ? 1 : 2;
+    const int wmv = g.M % 128 == 0 ? 2 : 1;
+    const int bm = 64 * wmv, bn = 256 / wmv;
+    const int ctl = mi_cdiv(g.ncols, bn);
+    g.mtiles = g.M / bm; g.tiles = g.mtiles * ctl; g.fdM = make_fastdiv(g.mtiles);
+    if (g.bn_part) g.bn_np = ctl * (bn / 64);
+    size_t lds = (size_t)nbuf * (bm * 128 + bn * 128);
+    const size_t img = (size_t)4 * 64 * 144;       // the epilogue's four wave images (fp32 form: 4 x 32 x 272, smaller)
+    if (lds < img) lds = img;
     static int attr_set = 0;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)cl_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * 128 + 128 * 128)) != hipSuccess ||
-            hipFuncSetAttribute((const void *)cl_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 * 128 + 128 * 128)) != hipSuccess) {
-            mi_record_error("cl_fwd_kernel", "cannot raise the dynamic LDS limit");
+        if (hipFuncSetAttribute((const void *)cl_conv_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * 128) != hipSuccess ||
+            hipFuncSetAttribute((const void *)cl_conv_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (64 + 256) * 128) != hipSuccess) {
+            mi_record_error("cl_conv_kernel", "cannot raise the dynamic LDS limit");
             return -1;
         }
         attr_set = 1;
     }
-    if (mb == 4) hipLaunchKernelGGL(cl_fwd_kernel<4>, dim3(g.tiles), dim3(256), lds, st, (const u16 *)a_tiles, (const u16 *)xp, (u16 *)y, g);
-    else hipLaunchKernelGGL(cl_fwd_kernel<2>, dim3(g.tiles), dim3(256), lds, st, (const u16 *)a_tiles, (const u16 *)xp, (u16 *)y, g);
+    mi_prof_begin(st, MI_FAM_PCONV, flops, bytes);
+#define CL_LAUNCH(WM_, NB_) hipLaunchKernelGGL((cl_conv_kernel<WM_, NB_>), dim3(g.tiles), dim3(256), lds, st, A, In, Out, g)
+    if (wmv == 2 && nbuf == 2) CL_LAUNCH(2, 2);
+    else if (wmv == 2) CL_LAUNCH(2, 1);
+    else if (nbuf == 2) CL_LAUNCH(1, 2);
+    else CL_LAUNCH(1, 1);
+#undef CL_LAUNCH
     mi_prof_end(st);
-    MI_LAUNCH_CHECK("cl_fwd_kernel");
+    MI_LAUNCH_CHECK("cl_conv_kernel");
     return 0;
+}
+
+extern "C" {
+/* shapes the channel-last kernels cover: 3x3, stride 1 or 2, channel counts a multiple of 64 (op 0 forward, 1 dgrad: stride 1 only) */
+int mid_cl_supported(int op, int N, int C, int H, int K, int stride) {
+    if (stride != 1 && stride != 2) return 0;
+    if (op == 1 && stride != 1) return 0;
+    if (H % stride || H / stride < 2 || H > 240) return 0;
+    if (C % 64 || K % 64) return 0;
+    const double inb = (double)N * (stride == 2 ? 4.0 * (H / 2 + 1) * (H / 2 + 1) : (double)(H + 2) * (H + 2)) * (op == 0 ? C : K) * 2;
+    if (inb >= 4294000000.0 || (double)N * K * (H / stride) * (H / stride) >= 2147480000.0 || (double)N * C * H * H >= 2147480000.0) return 0; /* 32-bit byte offsets */
+    return 1;
+}
+/* bytes of the re-laid operand: forward input (stride 1: one plane with a halo of 1; stride 2: four parity planes), or (op 1) the
+ * output gradient of a stride-1 dgrad (one plane with a halo of 1, K channels) */
+size_t mid_cl_operand_bytes(int op, int N, int C, int H, int K, int stride) {
+    if (op == 1) return (size_t)N * (H + 2) * (H + 2) * K * 2;
+    if (stride == 2) return (size_t)N * 4 * (H / 2 + 1) * (H / 2 + 1) * C * 2;
+    return (size_t)N * (H + 2) * (H + 2) * C * 2;
+}
+/* x (bf16 NCHW, C channels, H x H) -> the padded channel-last operand; the halo of xp must be zero (zero the buffer once when it is made).
+ * parity != 0: the four parity planes of a stride-2 forward; else one plane with a halo of 1 */
+int mid_cl_relayout(mid_stream s, const void *x, void *xp, int N, int C, int H, int parity) {
+    if (parity) {
+        const int Ho = H / 2;
+        hipLaunchKernelGGL(cl_relayout_kernel<1>, dim3(C / 64, Ho, N), dim3(256), (size_t)2 * H * 72 * 2, (hipStream_t)s, (const u16 *)x, (u16 *)xp, C, H, H, Ho + 1, Ho + 1, 0, 0);
+    } else {
+        hipLaunchKernelGGL(cl_relayout_kernel<0>, dim3(C / 64, H, N), dim3(256), (size_t)H * 72 * 2, (hipStream_t)s, (const u16 *)x, (u16 *)xp, C, H, H, H + 2, H + 2, 1, 1);
+    }
+    MI_LAUNCH_CHECK("cl_relayout_kernel");
+    return 0;
+}
+/* y (bf16 NCHW) = conv3x3 (stride 1 or 2, pad 1) of the re-laid input xp with a_tiles = the forward k-step tiles [t][c/64][K][64]
+ * (mid_conv_prelayout_all_bf16 / mid_bf16_prelayout_fwd); parts (optional): BN statistics partials as mid_conv_fwd_bf16 leaves them */
+int mid_cl_fwd(mid_stream s, const void *xp, const void *a_tiles, void *y, int N, int C, int H, int K, int stride, mid_bn_parts *parts) {
+    if (parts) parts->nparts = 0;
+    if (!mid_cl_supported(0, N, C, H, K, stride)) { mi_record_error("mid_cl_fwd", "shape not covered"); return -2; }
+    ClArgs g = {};
+    g.Cin = C; g.M = K; g.GH = H / stride; g.GW = H / stride; g.P = g.GH * g.GW; g.ntaps = 9;
+    if (stride == 2) {
+        const int Hp = g.GH + 1;
+        g.img_rows = 4 * Hp; g.Wp = Hp;
+        for (int t = 0; t < 9; t++) {
+            const int r = t / 3, sx = t % 3, q = 2 * ((r + 1) & 1) + ((sx + 1) & 1);
+            g.tap_delta[t] = (uint32_t)(((q * Hp + (r > 0)) * Hp + (sx > 0)) * C) * 2u;
+            g.tap_w[t] = t;
+        }
+    } else {
+        g.img_rows = H + 2; g.Wp = H + 2;
+        for (int t = 0; t < 9; t++) { g.tap_delta[t] = (uint32_t)(((t / 3) * g.Wp + (t % 3)) * C) * 2u; g.tap_w[t] = t; }
+    }
+    const int bn = K % 128 == 0 ? 128 : 256;
+    const int ctl = mi_cdiv(N * g.P, bn);
+    if (parts && parts->buf && parts->floats >= (size_t)3 * ctl * (bn / 64) * K) { g.bn_part = parts->buf; parts->nparts = ctl * (bn / 64); }
+    return cl_launch((hipStream_t)s, (const u16 *)a_tiles, (const u16 *)xp, (u16 *)y, g, N, 2.0 * 9 * (double)N * g.P * C * K,
+                     2.0 * ((double)N * C * H * H + (double)N * g.P * K) + 4.0 * 9 * C * K);
+}
+/* dx (bf16 NCHW, C channels) = the stride-1 dgrad of dyp = dY re-laid with a halo of 1 (K channels), a_tiles = the dgrad k-step tiles
+ * [t][k/64][C][64]; addend (optional, bf16 NCHW like dx; may be dx itself): added before the one rounding */
+int mid_cl_dgrad(mid_stream s, const void *dyp, const void *a_tiles, void *dx, const void *addend, int N, int C, int H, int K) {
+    if (!mid_cl_supported(1, N, C, H, K, 1)) { mi_record_error("mid_cl_dgrad", "shape not covered"); return -2; }
+    ClArgs g = {};
+    g.Cin = K; g.M = C; g.GH = H; g.GW = H; g.P = H * H; g.ntaps = 9;
+    g.img_rows = H + 2; g.Wp = H + 2;
+    for (int t = 0; t < 9; t++) { // dx(h, w) takes tap (r, s) from dY(h + 1 - r, w + 1 - s): padded row h + 2 - r
+        g.tap_delta[t] = (uint32_t)(((2 - t / 3) * g.Wp + (2 - t % 3)) * K) * 2u;
+        g.tap_w[t] = t;
+    }
+    g.addend = (const u16 *)addend;
+    return cl_launch((hipStream_t)s, (const u16 *)a_tiles, (const u16 *)dyp, (u16 *)dx, g, N, 2.0 * 9 * (double)N * g.P * C * K,
+                     2.0 * ((double)N * K * g.P + (double)N * C * g.P * (addend ? 2 : 1)) + 4.0 * 9 * C * K);
 }
 }

@@ -1324,6 +1324,8 @@ int mid_bf16_supported(int op, int N, int C, int H, int K, int k, int stride) { 
 size_t mid_bf16_part_floats(int N, int C, int H, int K, int k, int stride) { return mi_bgemm_part_floats(N, C, H, K, k, stride); }
 /* one layer's weights KCRS fp32 -> the bf16 k-step tiles of the forward pass [t][c/64][K][64] (what mid_conv_prelayout_all_bf16 makes for a table) */
 int mid_bf16_prelayout_fwd(mid_stream s, const float *w, void *out, int K, int C, int k) { return bg_prelayout_one((hipStream_t)s, w, (u16 *)out, nullptr, K, C, k); }
+/* ... and of the dgrad [t][k/64][C][64] */
+int mid_bf16_prelayout_dgrad(mid_stream s, const float *w, void *out, int K, int C, int k) { return bg_prelayout_one((hipStream_t)s, w, nullptr, (u16 *)out, K, C, k); }
 int mid_conv_prelayout_all_bf16(mid_stream s, const mid_wt_entry *entries_dev, const int *tile_entry_dev, int ntiles) {
     if (ntiles <= 0) return 0;
     hipLaunchKernelGGL(bg_wt_all_kernel, dim3(ntiles), dim3(256), 0, (hipStream_t)s, entries_dev, tile_entry_dev);

@@ -136,12 +136,17 @@ int mid_conv_dgrad_bf16(mid_stream s, mid_workspace *ws, const float *w, const v
                         int H, int K, int k, int stride);
 int mid_conv_wgrad_bf16(mid_stream s, mid_workspace *ws, const void *x, const void *dy, float *dw, int N, int C, int H, int K, int k,
                         int stride);
-/* ---- 3x3 / stride-2 forward on channel-last padded parity planes (kernels_cl_bf16.hip): both operands by LDS-DMA, no transposes ---- */
+/* ---- 3x3 convolutions of the bf16 path on channel-last, zero-padded operands (kernels_cl_bf16.hip): both operands global -> LDS by
+ * LDS-DMA, no transposes, no masks.  op 0 forward (stride 1 or 2), op 1 dgrad (stride 1) ---- */
 int mid_bf16_prelayout_fwd(mid_stream s, const float *w, void *out, int K, int C, int k);
-int mid_cl_fwd_supported(int N, int C, int H, int K);
-size_t mid_cl_xp_bytes(int N, int C, int H);
-int mid_cl_s2d(mid_stream s, const void *x, void *xp, int N, int C, int H); /* xp's halo must be zero: zero the buffer once */
-int mid_cl_fwd(mid_stream s, const void *xp, const void *a_tiles, void *y, int N, int C, int H, int K, mid_bn_parts *parts);
+int mid_bf16_prelayout_dgrad(mid_stream s, const float *w, void *out, int K, int C, int k);
+int mid_cl_supported(int op, int N, int C, int H, int K, int stride);
+size_t mid_cl_operand_bytes(int op, int N, int C, int H, int K, int stride);
+/* x (bf16 NCHW, C channels, H x H) -> padded channel-last; parity != 0: the four parity planes of a stride-2 forward.  The halo of xp
+ * must be zero: zero the buffer once when it is made (the kernel writes the interior only) */
+int mid_cl_relayout(mid_stream s, const void *x, void *xp, int N, int C, int H, int parity);
+int mid_cl_fwd(mid_stream s, const void *xp, const void *a_tiles, void *y, int N, int C, int H, int K, int stride, mid_bn_parts *parts);
+int mid_cl_dgrad(mid_stream s, const void *dyp, const void *a_tiles, void *dx, const void *addend, int N, int C, int H, int K);
 /* the 7x7 stride-2 stem (3 -> 64 channels) on the bf16 matrix cores (kernels_stem_bf16.hip): image and weights rounded to
  * bf16, fp32 accumulation, fp32 output / output gradient.  xp = the image as zero-padded parity planes (written by the
  * forward, read again by the weight gradient); scratch = wave partials + re-laid weights (mid_stem_bf16_part_floats). */

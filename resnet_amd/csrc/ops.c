@@ -316,19 +316,33 @@ int mi_debug_bn_merge(int R, int C, float *means, float *vars, float *dgamma, fl
     return rc;
 }
 
-/* the 3x3 / stride-2 forward convolution of the bf16 path on channel-last padded parity planes (kernels_cl_bf16.hip): x re-laid, weights
- * re-laid, then the LDS-DMA kernel.  -2: shape not covered (C % 64, K % 128, output plane % 4). */
-int mi_op_conv_fwd_bf16_cl(const void *x, const float *w, void *y, int N, int C, int H, int K) {
-    if (!mid_cl_fwd_supported(N, C, H, K)) return -2;
+/* the 3x3 convolutions of the bf16 path on channel-last zero-padded operands (kernels_cl_bf16.hip): operand re-laid, weights re-laid,
+ * then the LDS-DMA kernel.  Same tensors and semantics as mi_op_conv_fwd_bf16 / mi_op_conv_dgrad_bf16 with k = 3.  -2: shape not covered */
+int mi_op_conv_fwd_bf16_cl(const void *x, const float *w, void *y, int N, int C, int H, int K, int stride) {
+    if (!mid_cl_supported(0, N, C, H, K, stride)) return -2;
     mid_stream st = mi_global()->compute;
-    const size_t xb = mid_cl_xp_bytes(N, C, H);
+    const size_t xb = mid_cl_operand_bytes(0, N, C, H, K, stride);
     void *xp = mid_malloc(xb), *at = mid_malloc((size_t)9 * C * K * 2);
     if (!xp || !at) { mid_free(xp); mid_free(at); return -3; }
     mid_memset(xp, 0, xb, st);
     int rc = mid_bf16_prelayout_fwd(st, w, at, K, C, 3);
-    if (!rc) rc = mid_cl_s2d(st, x, xp, N, C, H);
-    if (!rc) rc = mid_cl_fwd(st, xp, at, y, N, C, H, K, NULL);
+    if (!rc) rc = mid_cl_relayout(st, x, xp, N, C, H, stride == 2);
+    if (!rc) rc = mid_cl_fwd(st, xp, at, y, N, C, H, K, stride, NULL);
     rc = finish(rc);
     mid_free(xp); mid_free(at);
+    return rc;
+}
+int mi_op_conv_dgrad_bf16_cl(const float *w, const void *dy, void *dx, int N, int C, int H, int K, int to_add) {
+    if (!mid_cl_supported(1, N, C, H, K, 1)) return -2;
+    mid_stream st = mi_global()->compute;
+    const size_t yb = mid_cl_operand_bytes(1, N, C, H, K, 1);
+    void *dyp = mid_malloc(yb), *at = mid_malloc((size_t)9 * C * K * 2);
+    if (!dyp || !at) { mid_free(dyp); mid_free(at); return -3; }
+    mid_memset(dyp, 0, yb, st);
+    int rc = mid_bf16_prelayout_dgrad(st, w, at, K, C, 3);
+    if (!rc) rc = mid_cl_relayout(st, dy, dyp, N, K, H, 0);
+    if (!rc) rc = mid_cl_dgrad(st, dyp, at, dx, to_add ? dx : NULL, N, C, H, K);
+    rc = finish(rc);
+    mid_free(dyp); mid_free(at);
     return rc;
 }

@@ -204,15 +204,24 @@ class Ops:
         self._chk(self.L.mi_op_conv_fwd_bf16(dx.ptr, dw.ptr, dy.ptr, N, Cc, H, K, k, stride), "conv_fwd_bf16")
         return self.get_t(dy, BF)
 
-    def conv_fwd_bf16_cl(self, x, w):
-        """3x3 stride-2 forward on channel-last padded parity planes (kernels_cl_bf16.hip)"""
+    def conv_fwd_bf16_cl(self, x, w, stride):
+        """3x3 forward on channel-last zero-padded operands (kernels_cl_bf16.hip)"""
         N, Cc, H, _ = x.shape
         K = w.shape[0]
         BF = B.MI_DTYPE_BF16
         dx, dw = self.dev_t(x, BF), self.dev(w)
-        dy = self.new_t((N, K, H // 2, H // 2), BF)
-        self._chk(self.L.mi_op_conv_fwd_bf16_cl(dx.ptr, dw.ptr, dy.ptr, N, Cc, H, K), "conv_fwd_bf16_cl")
+        dy = self.new_t((N, K, H // stride, H // stride), BF)
+        self._chk(self.L.mi_op_conv_fwd_bf16_cl(dx.ptr, dw.ptr, dy.ptr, N, Cc, H, K, stride), "conv_fwd_bf16_cl")
         return self.get_t(dy, BF)
+
+    def conv_dgrad_bf16_cl(self, w, dy, H, dx_init=None):
+        K, Cc, k, _ = w.shape
+        N = dy.shape[0]
+        BF = B.MI_DTYPE_BF16
+        dw_, ddy = self.dev(w), self.dev_t(dy, BF)
+        ddx = self.dev_t(dx_init, BF) if dx_init is not None else self.new_t((N, Cc, H, H), BF)
+        self._chk(self.L.mi_op_conv_dgrad_bf16_cl(dw_.ptr, ddy.ptr, ddx.ptr, N, Cc, H, K, 0 if dx_init is None else 1), "conv_dgrad_bf16_cl")
+        return self.get_t(ddx, BF)
 
     def conv_dgrad_bf16(self, w, dy, H, stride, dx_init=None):
         K, Cc, k, _ = w.shape

@@ -584,30 +584,34 @@ def test_resnet50_bf16_every_block_and_both_bn_backward_routes(oracle):
     assert max(errs) <= R50_BF16_FUSED_VS_NOT, max(errs)
 
 
-# (C, H, K, N): 3x3 stride-2 layers for the channel-last kernel (C % 64, K % 128, output plane % 4)
-CL_SHAPES = [(128, 56, 128, 2), (256, 56, 512, 1), (256, 28, 256, 3), (512, 28, 1024, 3), (64, 16, 128, 5), (128, 8, 128, 4), (128, 8, 256, 3), (64, 4, 128, 7)]
+# (C, H, K, stride, N): 3x3 layers for the channel-last kernels (channels % 64): every plane size of the benchmark network, 64-row and
+# 128-row tiles, ragged column tiles, planes that are not a multiple of 4 pixels (2-byte stores)
+CL_SHAPES = [(128, 56, 128, 2, 2), (256, 56, 512, 2, 1), (256, 28, 256, 2, 3), (512, 28, 1024, 2, 3), (512, 14, 512, 2, 2), (1024, 14, 2048, 2, 1),
+             (64, 56, 64, 1, 2), (128, 28, 128, 1, 3), (256, 14, 256, 1, 3), (512, 7, 512, 1, 5), (64, 8, 64, 1, 4), (128, 8, 128, 2, 4),
+             (128, 4, 128, 1, 4), (64, 10, 192, 1, 3), (64, 6, 64, 2, 5)]
+CL_IDS = ["C%d_H%d_K%d_s%d_N%d" % s for s in CL_SHAPES]
 
 
-@pytest.mark.parametrize("shape", CL_SHAPES, ids=["C%d_H%d_K%d_N%d" % s for s in CL_SHAPES])
-@pytest.mark.parametrize("mb", ["auto", "2", "4"])
-def test_conv_fwd_bf16_channel_last(ops, oracle, shape, mb):
-    """kernels_cl_bf16.hip: x re-laid once as zero-padded channel-last parity planes, both operands by LDS-DMA; both wave-tile shapes
-    (RESNET_MI_CL_MB is read once per process, so the forced ones run in a child process).  Same oracle, same band as the NCHW kernel."""
-    C, H, K, N = shape
-    if mb != "auto":
-        import subprocess
-        import sys
-        code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_bf16 as t, conftest; "
-                "from resnet_amd.ops import Ops; from oracle.oracle_py import Oracle; "
-                "t.test_conv_fwd_bf16_channel_last(Ops(), Oracle('f32'), %r, 'auto')")
-        here = os.path.dirname(os.path.abspath(__file__))
-        r = subprocess.run([sys.executable, "-c", code % (os.path.dirname(here), here, shape)], env=dict(os.environ, RESNET_MI_CL_MB=mb),
-                           capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
-        return
+@pytest.mark.parametrize("shape", CL_SHAPES, ids=CL_IDS)
+def test_conv_fwd_bf16_channel_last(ops, oracle, shape):
+    """kernels_cl_bf16.hip, forward: x re-laid once as zero-padded channel-last planes (four parity planes for stride 2), both operands by
+    LDS-DMA.  Same oracle, same band as the NCHW kernel."""
+    C, H, K, stride, N = shape
     x = bf16_round(rand((N, H, H, C), 7))
     w = bf16_round(rand((K, C, 3, 3), 8, scale=(2.0 / (9 * (C + K))) ** 0.5))
-    ref = oracle.conv_fwd(x, w, 2)
-    got = ops.conv_fwd_bf16_cl(nchw(x), w)
+    ref = oracle.conv_fwd(x, w, stride)
+    got = ops.conv_fwd_bf16_cl(nchw(x), w, stride)
     check_bf(nhwc(got), ref, "channel-last conv fwd %s" % (shape,))
-    assert np.array_equal(got, ops.conv_fwd_bf16(nchw(x), w, 2)) or rel_l2(got, ops.conv_fwd_bf16(nchw(x), w, 2)) < 2e-3
+
+
+@pytest.mark.parametrize("shape", [s for s in CL_SHAPES if s[3] == 1], ids=[i for s, i in zip(CL_SHAPES, CL_IDS) if s[3] == 1])
+@pytest.mark.parametrize("with_addend", [0, 1])
+def test_conv_dgrad_bf16_channel_last(ops, oracle, shape, with_addend):
+    """... and the stride-1 dgrad: dY re-laid with a halo of 1, the shortcut gradient (toAdd, resnet.cu:2157) added before the one rounding"""
+    C, H, K, stride, N = shape
+    w = bf16_round(rand((K, C, 3, 3), 8, scale=(2.0 / (9 * (C + K))) ** 0.5))
+    dy = bf16_round(rand((N, H, H, K), 9))
+    addend = bf16_round(rand((N, H, H, C), 10)) if with_addend else None
+    ref = oracle.conv_dgrad(w, dy, H, 1, dx_init=addend) if with_addend else oracle.conv_dgrad(w, dy, H, 1)
+    got = ops.conv_dgrad_bf16_cl(w, nchw(dy), H, dx_init=nchw(addend) if with_addend else None)
+    check_bf(nhwc(got), ref, "channel-last conv dgrad %s" % (shape,))
