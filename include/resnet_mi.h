@@ -397,9 +397,9 @@ int mi_op_conv_dgrad_bn_bwd_bf16(const float *w_kcrs, const void *dy, const void
                                  const float *vars, float eps, void *bn_dx, float *dgamma, float *dbeta);
 /* 3x3 convolutions of the bf16 path on channel-last, zero-padded operands (round 3; kernels_cl_bf16.hip): the operand is re-laid once
  * (one plane with a halo of 1, or four parity planes for stride 2), both MFMA operands then go global -> LDS by LDS-DMA.  Same tensors
- * and semantics as mi_op_conv_fwd_bf16 / mi_op_conv_dgrad_bf16 with k = 3 (dgrad: stride 1); -2: shape not covered (channels % 64) */
+ * and semantics as mi_op_conv_fwd_bf16 / mi_op_conv_dgrad_bf16 with k = 3; -2: shape not covered (channels % 64) */
 int mi_op_conv_fwd_bf16_cl(const void *x_bf16, const float *w_kcrs, void *y_bf16, int N, int C, int H, int K, int stride);
-int mi_op_conv_dgrad_bf16_cl(const float *w_kcrs, const void *dy_bf16, void *dx_bf16, int N, int C, int H, int K, int to_add);
+int mi_op_conv_dgrad_bf16_cl(const float *w_kcrs, const void *dy_bf16, void *dx_bf16, int N, int C, int H, int K, int stride, int to_add); /* stride 2: C % 128, no to_add */
 /* the same chain in fp32 storage: dgrads with stride 1 on the MFMA implicit-GEMM route do the reduction in their epilogue.  Image tensors
  * fp32.  Returns < 0 on error, else the number of partial rows the dgrad left (0 = separate pass). */
 int mi_op_conv_dgrad_bn_bwd_f32(const float *w_kcrs, const float *dy, const float *addend, float *gated, int N, int C, int H, int K, int k,

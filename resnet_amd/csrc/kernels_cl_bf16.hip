@@ -86,6 +86,36 @@ cl_relayout_kernel(const u16 *__restrict__ x, u16 *__restrict__ xp, int C, int H
     }
 }
 
+// The single-plane form again, tiled for the memory system: a block moves 64 channels x 64 consecutive pixels of one image -- in: 128-byte
+// runs of a channel plane (16-byte loads at any 2-byte alignment: gfx950 serves them at the streaming rate), out: 128-byte channel runs.
+typedef u32x4 __attribute__((aligned(2))) u32x4_u2;
+__global__ void __launch_bounds__(256)
+cl_relayout64_kernel(const u16 *__restrict__ x, u16 *__restrict__ xp, int C, int P, int W, int Hp, int Wp, int yoff, int xoff, FastDiv fdW) {
+    __shared__ __attribute__((aligned(16))) u16 tile[64 * 72];  // [pixel][64 channels], pitch 72
+    const int c0 = blockIdx.x * 64, p0 = blockIdx.y * 64, n = blockIdx.z;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int idx = threadIdx.x + 256 * u, cc = idx >> 3, part = idx & 7;
+        // (pixels past the plane's end are loaded from the next plane / the tensor's guard bytes and never stored)
+        const u32x4 v = *(const u32x4_u2 *)(x + ((size_t)n * C + c0 + cc) * P + p0 + part * 8);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            tile[(part * 8 + 2 * e) * 72 + cc] = (u16)(v[e] & 0xffffu);
+            tile[(part * 8 + 2 * e + 1) * 72 + cc] = (u16)(v[e] >> 16);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int idx = threadIdx.x + 256 * u, px = idx >> 3, piece = idx & 7;
+        const int p = p0 + px;
+        if (p < P) {
+            const uint32_t y = fd_div((uint32_t)p, fdW), xx = (uint32_t)p - y * W;
+            *(u32x4 *)(xp + (((size_t)n * Hp + y + yoff) * Wp + xx + xoff) * C + c0 + piece * 8) = *(const u32x4 *)(tile + px * 72 + piece * 8);
+        }
+    }
+}
+
 // Out[m][col] = sum over taps t, channels c:  A[tap_w[t]][c][m] * In[pixel(col) + tap_delta[t]][c]      (NCHW output, bf16)
 // WM: waves along M.  2: workgroup tile 128 (M) x 128 (pixels), waves 2 x 2; 1: 64 x 256, waves 1 x 4 (64-channel layers).  Wave tile 64 x 64.
 // NBUF: operand buffers (2: the DMA of k-step i + 1 runs under the MFMAs of k-step i, one barrier per k-step; 1: half the LDS, two
@@ -323,6 +353,163 @@ cl_conv_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ In, u16 *__r
     else drain(std::integral_constant<int, 4>{});
 }
 
+// Stride-2 dgrad.  dx (2a + ph, 2b + pw) takes the taps whose parity matches: ph = 0 -> r = 1 (dY row a); ph = 1 -> r = 0 (row a + 1) and
+// r = 2 (row a); the same in the columns.  A workgroup owns ONE row parity (blockIdx.y) and BOTH column parities of a 128 (channels) x 128
+// (grid pixels (n, a, b)) tile: two accumulator sets, filled one after the other from the same re-laid dY (K channels last, one zero row
+// / column at the far end: the taps look down / right) -- so that in the epilogue the two results of a grid pixel are neighbours,
+// dx(.., 2b) and dx(.., 2b + 1), and a lane stores runs of 8 / 4 consecutive output pixels instead of scattering 2-byte elements at
+// stride 2 (what the NCHW kernel's four parity classes do: a third of the b3 projection's dgrad was its epilogue).
+struct ClD2Args {
+    int K, C;                       // reduction channels (of dY), output channels (of dx)
+    int Ho, Wo, P, ncols;           // dY grid per image, P = Ho * Wo, ncols = N * P
+    int Wp;                         // padded row length of the re-laid dY (Wo + 1); rows per image Ho + 1
+    int mtiles, tiles;
+    FastDiv fdP, fdWo, fdM;
+    int cpx;                        // grid pixels per lane and store in the epilogue: 4 / 2 / 1 (Wo % cpx == 0)
+};
+__global__ void __launch_bounds__(256, 2) // (two waves per SIMD: 128 accumulator registers + operands must fit 256)
+cl_dgrad2_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ In, u16 *__restrict__ Out, const ClD2Args g) {
+    constexpr int ABYTES = 128 * 128, BBYTES = 128 * 128, BUF = ABYTES + BBYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char cl_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ph = 1 - (int)blockIdx.y;            // the heavier row parity (two row taps) first
+    uint32_t L = blockIdx.x;
+    {
+        const uint32_t per = (uint32_t)g.tiles >> 3;
+        if (L < per * 8) L = (L & 7) * per + (L >> 3);
+    }
+    const uint32_t ct = fd_div(L, g.fdM);
+    const int m0 = (int)(L - ct * g.mtiles) * 128, n0 = (int)ct * 128;
+
+    f32x16 acc[2][2][2];                            // [column parity][i][j]
+#pragma unroll
+    for (int w = 0; w < 2; w++)
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[w][i][j][r] = 0.f;
+
+    const int prow = tid >> 3, pchunk = tid & 7;
+    uint32_t boff[4], aoff[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int row = prow + 32 * u;
+        const uint32_t j = (uint32_t)min(n0 + row, g.ncols - 1);
+        const uint32_t n = fd_div(j, g.fdP), p = j - n * g.P;
+        const uint32_t a = fd_div(p, g.fdWo), b = p - a * g.Wo;
+        boff[u] = ((n * (uint32_t)(g.Ho + 1) + a) * g.Wp + b) * (uint32_t)g.K * 2u + (uint32_t)((pchunk ^ cl_key(row)) * 16);
+        aoff[u] = (uint32_t)(row * 128 + ((pchunk ^ cl_key(row)) * 16));
+    }
+    // tap list: column parity 0 (s = 1) first, then column parity 1 (s = 0: dY column b + 1, s = 2: column b); per row tap
+    const int nrt = ph ? 2 : 1;                    // row taps: ph = 1: r = 0 (row a + 1), r = 2 (row a); ph = 0: r = 1
+    const int cpt = g.K / 64;
+    const int nt0 = nrt * cpt, ntiles = 3 * nrt * cpt; // k-steps of column parity 0 / in all
+    int ld_i = 0, ld_c = 0;                        // tap index in the list (0 .. 3 nrt - 1), channel chunk
+    auto issue = [&](const int buf) {
+        // tap ld_i: [0, nrt): pw = 0, row tap ld_i; [nrt, 3 nrt): pw = 1, row tap (ld_i - nrt) >> 1, column tap (ld_i - nrt) & 1
+        const int pw1 = ld_i >= nrt;
+        const int rt = pw1 ? (ld_i - nrt) >> 1 : ld_i, ctp = pw1 ? (ld_i - nrt) & 1 : 0;
+        const int r = ph ? 2 * rt : 1, dh = ph ? 1 - rt : 0;
+        const int sx = pw1 ? 2 * ctp : 1, dw = pw1 ? 1 - ctp : 0;
+        const unsigned char *fa = (const unsigned char *)(Aop + ((size_t)((3 * r + sx) * cpt + ld_c) * g.C + m0) * 64);
+        const unsigned char *fb = (const unsigned char *)In + (uint32_t)((dh * g.Wp + dw) * g.K + ld_c * 64) * 2u;
+        unsigned char *la = cl_smem + buf * BUF + wave * 1024, *lb = cl_smem + buf * BUF + ABYTES + wave * 1024;
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(fa + aoff[u]),
+                                             (__attribute__((address_space(3))) void *)(la + u * 4096), 16, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(fb + boff[u]),
+                                             (__attribute__((address_space(3))) void *)(lb + u * 4096), 16, 0, 0);
+        if (++ld_c == cpt) { ld_c = 0; ld_i++; }
+    };
+    const int fr = lane & 31, fk = lane >> 5;
+    auto compute = [&](const int buf, auto w_tag) {
+        constexpr int W = decltype(w_tag)::value;
+        const unsigned char *as = cl_smem + buf * BUF, *bs = as + ABYTES;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            bf16x8 av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int row = wm * 64 + i * 32 + fr;
+                av[i] = *(const bf16x8 *)(as + row * 128 + (((2 * s + fk) ^ cl_key(row)) * 16));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int row = wn * 64 + j * 32 + fr;
+                bv[j] = *(const bf16x8 *)(bs + row * 128 + (((2 * s + fk) ^ cl_key(row)) * 16));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[W][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[j], av[i], acc[W][i][j], 0, 0, 0);
+        }
+    };
+    issue(0);
+    int it = 0;
+    for (; it < nt0; it++) {                       // column parity 0 (the DMA pipeline runs on into parity 1's first k-step)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        issue((it + 1) & 1);
+        compute(it & 1, std::integral_constant<int, 0>{});
+    }
+    for (; it < ntiles; it++) {                    // column parity 1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (it + 1 < ntiles) issue((it + 1) & 1);
+        compute(it & 1, std::integral_constant<int, 1>{});
+    }
+    __syncthreads();
+
+    // ---- epilogue: 32 channels at a time through a wave-private LDS image [32 channels][64 grid pixels][2 column parities] (bf16:
+    // 256 bytes per row + 16), drained with lanes running along a channel row ----
+    const int l31 = lane & 31, hh = lane >> 5;
+    constexpr int PITCH = 64 * 4 + 16;
+    unsigned char *img = cl_smem + wave * (32 * PITCH);
+    const int colw = n0 + wn * 64;
+    const int H = 2 * g.Ho, Wd = 2 * g.Wo;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) { // 4 consecutive grid pixels x 2 parities = 8 consecutive output pixels (where they share a row)
+                u32x4 v = {cl_pack2(acc[0][i][j][4 * q], acc[1][i][j][4 * q]), cl_pack2(acc[0][i][j][4 * q + 1], acc[1][i][j][4 * q + 1]),
+                           cl_pack2(acc[0][i][j][4 * q + 2], acc[1][i][j][4 * q + 2]), cl_pack2(acc[0][i][j][4 * q + 3], acc[1][i][j][4 * q + 3])};
+                *(u32x4 *)(img + l31 * PITCH + (j * 32 + 8 * q + 4 * hh) * 4) = v;
+            }
+        auto drain = [&](auto cpx_tag) {
+            constexpr int CPX = decltype(cpx_tag)::value; // grid pixels per lane: 2 CPX output pixels per store
+            constexpr int CPR = 64 / CPX, RPP = 64 / CPR;
+            const int c = lane % CPR, r0 = lane / CPR;
+            const int col = colw + c * CPX;
+            const bool ok = col < g.ncols;               // (ncols % CPX == 0: Wo % CPX == 0)
+            const uint32_t cc = ok ? (uint32_t)col : 0u;
+            const uint32_t n = fd_div(cc, g.fdP), p = cc - n * g.P;
+            const uint32_t a = fd_div(p, g.fdWo), b = p - a * g.Wo;
+            const size_t obase = ((size_t)n * g.C * H + (2 * a + ph)) * Wd + 2 * b;
+#pragma unroll
+            for (int ps = 0; ps < 32 / RPP; ps++) {
+                const int row = ps * RPP + r0;
+                const size_t o = obase + (size_t)(m0 + wm * 64 + i * 32 + row) * H * Wd;
+                const unsigned char *sp = img + row * PITCH + c * CPX * 4;
+                if constexpr (CPX == 4) { const u32x4 v = *(const u32x4 *)sp; if (ok) *(u32x4 *)(Out + o) = v; }
+                else if constexpr (CPX == 2) { const u32x2 v = *(const u32x2 *)sp; if (ok) *(u32x2 *)(Out + o) = v; }
+                else { const uint32_t v = *(const uint32_t *)sp; if (ok) *(uint32_t *)(Out + o) = v; }
+            }
+        };
+        if (g.cpx == 4) drain(std::integral_constant<int, 4>{});
+        else if (g.cpx == 2) drain(std::integral_constant<int, 2>{});
+        else drain(std::integral_constant<int, 1>{});
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 static int cl_launch(hipStream_t st, const u16 *A, const u16 *In, u16 *Out, ClArgs &g, int N, double flops, double bytes) {
     g.ncols = N * g.P;
@@ -385,9 +572,43 @@ int mid_cl_relayout(mid_stream s, const void *x, void *xp, int N, int C, int H, 
         const int Ho = H / 2;
         hipLaunchKernelGGL(cl_relayout_kernel<1>, dim3(C / 64, Ho, N), dim3(256), (size_t)2 * H * 72 * 2, (hipStream_t)s, (const u16 *)x, (u16 *)xp, C, H, H, Ho + 1, Ho + 1, 0, 0);
     } else {
-        hipLaunchKernelGGL(cl_relayout_kernel<0>, dim3(C / 64, H, N), dim3(256), (size_t)H * 72 * 2, (hipStream_t)s, (const u16 *)x, (u16 *)xp, C, H, H, H + 2, H + 2, 1, 1);
+        hipLaunchKernelGGL(cl_relayout64_kernel, dim3(C / 64, mi_cdiv(H * H, 64), N), dim3(256), 0, (hipStream_t)s, (const u16 *)x, (u16 *)xp, C, H * H, H, H + 2, H + 2, 1, 1, make_fastdiv(H));
     }
     MI_LAUNCH_CHECK("cl_relayout_kernel");
+    return 0;
+}
+/* dY (bf16 NCHW, K channels, Ho x Ho) -> channel-last with one zero row / column at the far end: the operand of the stride-2 dgrad */
+int mid_cl_relayout_end(mid_stream s, const void *dy, void *dyp, int N, int K, int Ho) {
+    hipLaunchKernelGGL(cl_relayout64_kernel, dim3(K / 64, mi_cdiv(Ho * Ho, 64), N), dim3(256), 0, (hipStream_t)s, (const u16 *)dy, (u16 *)dyp, K, Ho * Ho, Ho, Ho + 1, Ho + 1, 0, 0,
+                       make_fastdiv(Ho));
+    MI_LAUNCH_CHECK("cl_relayout64_kernel");
+    return 0;
+}
+size_t mid_cl_dgrad2_operand_bytes(int N, int K, int Ho) { return (size_t)N * (Ho + 1) * (Ho + 1) * K * 2; }
+int mid_cl_dgrad2_supported(int N, int C, int H, int K) {
+    if (H % 2 || H < 4 || H > 240 || C % 128 || K % 64) return 0;
+    if ((double)N * (H / 2 + 1) * (H / 2 + 1) * K * 2 >= 4294000000.0 || (double)N * C * H * H >= 2147480000.0) return 0;
+    return 1;
+}
+/* dx (bf16 NCHW, C channels, H x H) = the 3x3 stride-2 dgrad of dyp (mid_cl_relayout_end of dY, K channels, H/2 x H/2) with
+ * a_tiles = the dgrad k-step tiles [t][k/64][C][64].  Every element of dx is written (no addend). */
+int mid_cl_dgrad2(mid_stream s, const void *dyp, const void *a_tiles, void *dx, int N, int C, int H, int K) {
+    hipStream_t st = (hipStream_t)s;
+    if (!mid_cl_dgrad2_supported(N, C, H, K)) { mi_record_error("mid_cl_dgrad2", "shape not covered"); return -2; }
+    ClD2Args g = {};
+    g.K = K; g.C = C; g.Ho = H / 2; g.Wo = H / 2; g.P = g.Ho * g.Wo; g.ncols = N * g.P; g.Wp = g.Wo + 1;
+    g.fdP = make_fastdiv(g.P); g.fdWo = make_fastdiv(g.Wo);
+    g.cpx = g.Wo % 4 == 0 ? 4 : g.Wo % 2 == 0 ? 2 : 1;
+    g.mtiles = C / 128; g.tiles = g.mtiles * mi_cdiv(g.ncols, 128); g.fdM = make_fastdiv(g.mtiles);
+    static int attr_set = 0;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)cl_dgrad2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess) { mi_record_error("cl_dgrad2_kernel", "cannot raise the dynamic LDS limit"); return -1; }
+        attr_set = 1;
+    }
+    mi_prof_begin(st, MI_FAM_PCONV, 2.0 * 9 * (double)N * g.P * C * K, 2.0 * ((double)N * K * g.P + (double)N * C * H * H) + 4.0 * 9 * C * K);
+    hipLaunchKernelGGL(cl_dgrad2_kernel, dim3(g.tiles, 2), dim3(256), 65536, st, (const u16 *)a_tiles, (const u16 *)dyp, (u16 *)dx, g);
+    mi_prof_end(st);
+    MI_LAUNCH_CHECK("cl_dgrad2_kernel");
     return 0;
 }
 /* y (bf16 NCHW) = conv3x3 (stride 1 or 2, pad 1) of the re-laid input xp with a_tiles = the forward k-step tiles [t][c/64][K][64]

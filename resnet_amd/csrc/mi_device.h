@@ -147,6 +147,12 @@ size_t mid_cl_operand_bytes(int op, int N, int C, int H, int K, int stride);
 int mid_cl_relayout(mid_stream s, const void *x, void *xp, int N, int C, int H, int parity);
 int mid_cl_fwd(mid_stream s, const void *xp, const void *a_tiles, void *y, int N, int C, int H, int K, int stride, mid_bn_parts *parts);
 int mid_cl_dgrad(mid_stream s, const void *dyp, const void *a_tiles, void *dx, const void *addend, int N, int C, int H, int K);
+/* stride-2 dgrad: dY (K channels, H/2 x H/2) re-laid channel-last with one zero row / column at the far end, both column parities of dx in
+ * one workgroup (dense stores) */
+int mid_cl_dgrad2_supported(int N, int C, int H, int K);
+size_t mid_cl_dgrad2_operand_bytes(int N, int K, int Ho);
+int mid_cl_relayout_end(mid_stream s, const void *dy, void *dyp, int N, int K, int Ho);
+int mid_cl_dgrad2(mid_stream s, const void *dyp, const void *a_tiles, void *dx, int N, int C, int H, int K);
 /* the 7x7 stride-2 stem (3 -> 64 channels) on the bf16 matrix cores (kernels_stem_bf16.hip): image and weights rounded to
  * bf16, fp32 accumulation, fp32 output / output gradient.  xp = the image as zero-padded parity planes (written by the
  * forward, read again by the weight gradient); scratch = wave partials + re-laid weights (mid_stem_bf16_part_floats). */

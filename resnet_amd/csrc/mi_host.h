@@ -44,7 +44,12 @@ BatchExt *mi_batch_ext(Batch *b);
 void mi_batch_ext_free(Batch *b);
 
 /* parity copies of a striding block's conv inputs; *_valid: the last forward pass wrote the planes (the weight gradient may read them) */
-typedef struct { void *spatial, *proj; size_t spatial_bytes, proj_bytes; int spatial_valid, proj_valid; } MiParity;
+typedef struct {
+    void *spatial, *proj; size_t spatial_bytes, proj_bytes; int spatial_valid, proj_valid;
+    /* the stride-2 dgrads' output gradient re-laid channel-last with a zero row / column at the far end (kernels_cl_bf16.hip); the
+     * halo is zeroed once, when the buffers are made; NULL = that layer's dgrad stays on the NCHW kernel */
+    void *dye_spatial, *dye_proj;
+} MiParity;
 typedef struct MiCtx {
     mid_workspace ws;
     float *bn_ws;
@@ -82,6 +87,7 @@ typedef struct MiCtx {
     int params_dirty;            /* update_parameters ran since the last weight re-layout */
     unsigned long host_epoch_seen; /* the process-wide host-write count (mi_copy_to_device) that re-layout was made at */
     void *cur_par; size_t cur_par_bytes; int *cur_par_valid; /* parity buffer of the stride-2 convolution about to be launched */
+    void *cur_dye;               /* ... and the channel-last buffer for its output gradient (stride-2 dgrad), or NULL */
     char *dump_root;
     /* every device allocation of this trainer (freed by destroy_trainer) */
     void **allocs;

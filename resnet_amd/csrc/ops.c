@@ -332,7 +332,21 @@ int mi_op_conv_fwd_bf16_cl(const void *x, const float *w, void *y, int N, int C,
     mid_free(xp); mid_free(at);
     return rc;
 }
-int mi_op_conv_dgrad_bf16_cl(const float *w, const void *dy, void *dx, int N, int C, int H, int K, int to_add) {
+int mi_op_conv_dgrad_bf16_cl(const float *w, const void *dy, void *dx, int N, int C, int H, int K, int stride, int to_add) {
+    if (stride == 2) {
+        if (to_add || !mid_cl_dgrad2_supported(N, C, H, K)) return -2;
+        mid_stream st2 = mi_global()->compute;
+        const size_t yb2 = mid_cl_dgrad2_operand_bytes(N, K, H / 2);
+        void *dyp2 = mid_malloc(yb2), *at2 = mid_malloc((size_t)9 * C * K * 2);
+        if (!dyp2 || !at2) { mid_free(dyp2); mid_free(at2); return -3; }
+        mid_memset(dyp2, 0, yb2, st2);
+        int rc2 = mid_bf16_prelayout_dgrad(st2, w, at2, K, C, 3);
+        if (!rc2) rc2 = mid_cl_relayout_end(st2, dy, dyp2, N, K, H / 2);
+        if (!rc2) rc2 = mid_cl_dgrad2(st2, dyp2, at2, dx, N, C, H, K);
+        rc2 = finish(rc2);
+        mid_free(dyp2); mid_free(at2);
+        return rc2;
+    }
     if (!mid_cl_supported(1, N, C, H, K, 1)) return -2;
     mid_stream st = mi_global()->compute;
     const size_t yb = mid_cl_operand_bytes(1, N, C, H, K, 1);

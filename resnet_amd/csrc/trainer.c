@@ -367,6 +367,19 @@ static void size_workspaces(MiCtx *c, const Dims *d, ConvBlock **blocks, int N) 
             c->par[i].spatial_bytes = e1 * 2;
             c->par[i].spatial = (char *)mi_ctx_alloc(c, e1 * 2 + 2 * MI_GUARD) + MI_GUARD;
             if (b->projection) { c->par[i].proj_bytes = e2 * 2; c->par[i].proj = (char *)mi_ctx_alloc(c, e2 * 2 + 2 * MI_GUARD) + MI_GUARD; }
+            /* the stride-2 dgrads on channel-last dY (RESNET_MI_BF16_CL_DGRAD2=0: the NCHW kernel's four parity classes) */
+            if (!(getenv("RESNET_MI_BF16_CL_DGRAD2") && atoi(getenv("RESNET_MI_BF16_CL_DGRAD2")) == 0)) {
+                if (mid_cl_dgrad2_supported(N, b->reduced_depth, (int)H, b->reduced_depth)) {
+                    const size_t by = mid_cl_dgrad2_operand_bytes(N, b->reduced_depth, (int)H / 2);
+                    c->par[i].dye_spatial = mi_ctx_alloc(c, by);
+                    mid_memset(c->par[i].dye_spatial, 0, by, G.compute);
+                }
+                if (b->projection && mid_cl_dgrad2_supported(N, b->incoming_filters, (int)H, b->expanded_depth)) {
+                    const size_t by = mid_cl_dgrad2_operand_bytes(N, b->expanded_depth, (int)H / 2);
+                    c->par[i].dye_proj = mi_ctx_alloc(c, by);
+                    mid_memset(c->par[i].dye_proj, 0, by, G.compute);
+                }
+            }
         }
     }
     c->ws.wt_floats = wt; c->ws.part_floats = part;
@@ -746,7 +759,7 @@ void mi_trainer_poll_errors(Train_ResNet *t) {
  * stem: the 7x7 convolution keeps fp32 input / output in every storage type; only its BN output is an activation tensor */
 /* c->cur_par: parity copy of the NEXT stride-2 convolution's input (set by the caller); c->cur_par_valid: where the forward pass
  * records whether it really wrote the planes (it does only on the 16-byte staging route), read back by the weight gradient */
-static void set_cur_par(MiCtx *c, void *buf, size_t bytes, int *valid) { c->cur_par = buf; c->cur_par_bytes = bytes; c->cur_par_valid = valid; }
+static void set_cur_par(MiCtx *c, void *buf, size_t bytes, int *valid) { c->cur_par = buf; c->cur_par_bytes = bytes; c->cur_par_valid = valid; c->cur_dye = NULL; }
 static void unit_fwd(Train_ResNet *t, const float *in, const float *w, const BatchNorm *bn, Cache_BatchNorm *cache,
                      float *conv_out, float *act_out, const float *residual, int C, int H, int K, int k, int stride,
                      int relu, int stem) {
@@ -874,6 +887,15 @@ static void conv_dgrad_t(Train_ResNet *t, const float *w, const float *dy, float
     MiCtx *c = ctx_of(t);
     const mid_wt_entry *we = wt_lookup(c, w);
     c->ws.pre_dgrad = we ? we->dgrad : NULL;
+    if (c->dtype == MID_BF16 && stride == 2 && k == 3 && !addend && c->cur_dye && we && we->dgrad) {
+        /* stride-2 dgrad on channel-last dY: re-lay dY (K channels, H/2 x H/2) into the layer's zero-bordered buffer, then both column
+         * parities of dx per workgroup by LDS-DMA staged MFMAs (dense stores; 1.5-1.9x the NCHW kernel's four parity classes) */
+        ck(mid_cl_relayout_end(G.compute, dy, c->cur_dye, t->batch_size, K, H / 2), "dY re-layout (channel-last)");
+        ck(mid_cl_dgrad2(G.compute, c->cur_dye, we->dgrad, dx, t->batch_size, C, H, K), "convolution dgrad (bf16, channel-last, stride 2)");
+        c->fz_req_valid = 0;
+        c->ws.pre_dgrad = NULL;
+        return;
+    }
     if (c->dtype == MID_BF16 && c->fz_req_valid) { /* ... and the reduction pass of the BN' its output feeds */
         ck(mid_conv_dgrad_bn_bf16(G.compute, &c->ws, w, dy, dx, addend, t->batch_size, C, H, K, k, stride, &c->fz_req), "convolution dgrad + BN' reduction (bf16)");
         if (c->fz_req.nparts > 0) { c->fz_done = c->fz_req; c->fz_ready = 1; }
@@ -991,6 +1013,7 @@ void backwards_pass(Train_ResNet *t) {
             /* ReLU' of the block output (doActivationDeriv, :1934) is fused into the projection BN' as an external mask; that
              * pass also leaves relu'(out) * up in dk->output, which the expansion BN' then reads instead of up + mask */
             if (c->par) set_cur_par(c, c->par[i].proj, c->par[i].proj_bytes, &c->par[i].proj_valid); else set_cur_par(c, NULL, 0, NULL);
+            c->cur_dye = c->par ? c->par[i].dye_proj : NULL;
             unit_bwd(t, bin, b->projection, b->norm_projection, k->norm_post_projection, db->norm_projection,
                      k->transformed_residual, up, k->output_activated, 3, dk->output, dk->transformed_residual, s_proj, dbin, NULL,
                      db->projection, b->incoming_filters, H, b->expanded_depth, b->stride == 2 ? 3 : 1, b->stride, 0);
@@ -1017,6 +1040,7 @@ void backwards_pass(Train_ResNet *t) {
                               k->norm_post_reduced->means, k->norm_post_reduced->vars, k->post_reduced_activated, c->dtype, N, b->reduced_depth,
                               H * H, t->eps, 1), "BN recompute");
         if (c->par) set_cur_par(c, c->par[i].spatial, c->par[i].spatial_bytes, &c->par[i].spatial_valid); else set_cur_par(c, NULL, 0, NULL);
+        c->cur_dye = c->par ? c->par[i].dye_spatial : NULL;
         FZ_REQ(2, k->post_reduced, k->post_reduced_activated, k->norm_post_reduced->means); /* spatial dgrad -> reduction BN' */
         unit_bwd(t, k->post_reduced_activated, b->spatial, b->norm_spatial, k->norm_post_spatial, db->norm_spatial,
                  k->post_spatial, dk->post_spatial_activated, NULL, 1, NULL, dk->post_spatial, s_spa, dk->post_reduced_activated, NULL,

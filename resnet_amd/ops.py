@@ -214,13 +214,13 @@ class Ops:
         self._chk(self.L.mi_op_conv_fwd_bf16_cl(dx.ptr, dw.ptr, dy.ptr, N, Cc, H, K, stride), "conv_fwd_bf16_cl")
         return self.get_t(dy, BF)
 
-    def conv_dgrad_bf16_cl(self, w, dy, H, dx_init=None):
+    def conv_dgrad_bf16_cl(self, w, dy, H, dx_init=None, stride=1):
         K, Cc, k, _ = w.shape
         N = dy.shape[0]
         BF = B.MI_DTYPE_BF16
         dw_, ddy = self.dev(w), self.dev_t(dy, BF)
         ddx = self.dev_t(dx_init, BF) if dx_init is not None else self.new_t((N, Cc, H, H), BF)
-        self._chk(self.L.mi_op_conv_dgrad_bf16_cl(dw_.ptr, ddy.ptr, ddx.ptr, N, Cc, H, K, 0 if dx_init is None else 1), "conv_dgrad_bf16_cl")
+        self._chk(self.L.mi_op_conv_dgrad_bf16_cl(dw_.ptr, ddy.ptr, ddx.ptr, N, Cc, H, K, stride, 0 if dx_init is None else 1), "conv_dgrad_bf16_cl")
         return self.get_t(ddx, BF)
 
     def conv_dgrad_bf16(self, w, dy, H, stride, dx_init=None):

@@ -615,3 +615,18 @@ def test_conv_dgrad_bf16_channel_last(ops, oracle, shape, with_addend):
     ref = oracle.conv_dgrad(w, dy, H, 1, dx_init=addend) if with_addend else oracle.conv_dgrad(w, dy, H, 1)
     got = ops.conv_dgrad_bf16_cl(w, nchw(dy), H, dx_init=nchw(addend) if with_addend else None)
     check_bf(nhwc(got), ref, "channel-last conv dgrad %s" % (shape,))
+
+
+CL_D2_SHAPES = [(128, 56, 128, 2), (256, 56, 512, 1), (256, 28, 256, 3), (512, 28, 1024, 2), (512, 14, 512, 2), (1024, 14, 2048, 1), (128, 8, 128, 4), (128, 12, 64, 3), (256, 6, 128, 5)]
+
+
+@pytest.mark.parametrize("shape", CL_D2_SHAPES, ids=["C%d_H%d_K%d_N%d" % s for s in CL_D2_SHAPES])
+def test_conv_dgrad_s2_bf16_channel_last(ops, oracle, shape):
+    """the stride-2 dgrad on channel-last dY: one workgroup per row parity computes BOTH column parities, so dx is stored in runs of
+    consecutive pixels (row lengths a multiple of 8 / 4 / 2: 16- / 8- / 4-byte stores)"""
+    C, H, K, N = shape
+    w = bf16_round(rand((K, C, 3, 3), 8, scale=(2.0 / (9 * (C + K))) ** 0.5))
+    dy = bf16_round(rand((N, H // 2, H // 2, K), 9))
+    ref = oracle.conv_dgrad(w, dy, H, 2)
+    got = ops.conv_dgrad_bf16_cl(w, nchw(dy), H, stride=2)
+    check_bf(nhwc(got), ref, "channel-last conv dgrad s2 %s" % (shape,))

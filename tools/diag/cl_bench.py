@@ -25,7 +25,9 @@ for name, Cc, H, K, S in LAY:
     out = []
     ops_ = [("fwd nchw", lambda: L.mi_op_conv_fwd_bf16(xb, w, yb, N, Cc, H, K, 3, S)), ("fwd cl", lambda: L.mi_op_conv_fwd_bf16_cl(xb, w, yb, N, Cc, H, K, S))]
     if S == 1:
-        ops_ += [("dgrad nchw", lambda: L.mi_op_conv_dgrad_bf16(w, yb, xb, N, Cc, H, K, 3, 1, 0)), ("dgrad cl", lambda: L.mi_op_conv_dgrad_bf16_cl(w, yb, xb, N, Cc, H, K, 0))]
+        ops_ += [("dgrad nchw", lambda: L.mi_op_conv_dgrad_bf16(w, yb, xb, N, Cc, H, K, 3, 1, 0)), ("dgrad cl", lambda: L.mi_op_conv_dgrad_bf16_cl(w, yb, xb, N, Cc, H, K, 1, 0))]
+    else:
+        ops_ += [("dgrad nchw", lambda: L.mi_op_conv_dgrad_bf16(w, yb, xb, N, Cc, H, K, 3, 2, 0)), ("dgrad cl", lambda: L.mi_op_conv_dgrad_bf16_cl(w, yb, xb, N, Cc, H, K, 2, 0))]
     for which, fn in ops_:
         L.mi_prof_enable(1)
         for rep in range(4):
