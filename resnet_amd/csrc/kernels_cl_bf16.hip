@@ -29,6 +29,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16;
 
+int mi_igemm_wgrad_reduce(hipStream_t st, const float *part, float *dw, int K, int C, int k, int splits); // kernels_igemm.hip
+
 struct ClArgs {
     int Cin, M;                     // reduction channels per tap, output channels (rows of the product)
     int GH, GW, P, ncols;           // output grid per image, P = GH * GW, ncols = N * P
@@ -510,6 +512,199 @@ cl_dgrad2_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ In, u16 *_
     }
 }
 
+// Weight gradient:  dW[t][k][c] = sum over pixels  dY[k][pix] * X[pix + D_t][c].  The reduction runs over pixels, which is the CONTIGUOUS index of dY
+// (NCHW: the A operand as it lies, 128-byte rows of 64 pixels) and the ROW index of the channel-last input: the B fragments (8 consecutive
+// pixels of one channel per lane) are read TRANSPOSED from a [64 pixels][128 channels] LDS image with ds_read_b64_tr_b16 (per 16-lane group a
+// 4 row x 16 column block, delivered column-major), 256-byte rows XOR-swizzled so that both the DMA fill and the transposed reads are
+// conflict-free.  Workgroup tile 128 (k) x 128 (c) of ONE tap; the reduction = 64-pixel tiles that never cross an image (the tail tile of a
+// plane is padded: its missing pixels read a zero page on the B side, so whatever the A side picks up beyond the plane -- finite data of the
+// next plane -- is multiplied by zero), split over blockIdx.y; fp32 partials [split][t][k][c], summed in a fixed order by the second stage.
+typedef short cl_s16x4 __attribute__((ext_vector_type(4)));
+struct ClWgArgs {
+    int K, C;                       // dY channels (rows), input channels (columns)
+    int P, GW;                      // output pixels per image, output row length
+    int img_rows, Wp;               // padded input geometry as ClArgs
+    int ptiles;                     // reduction steps (CLW_KPX pixels) per image
+    int rtiles;                     // reduction tiles in all = N * ptiles
+    int rlen;                       // reduction tiles per split
+    int ctiles, mtiles;             // C / 128, K / 128
+    uint32_t tap_delta[9];
+    FastDiv fdGW, fdPt, fdM, fdS, fd9;
+    uint32_t splits, total8;        // splits in use; (tiles * splits) rounded down to a multiple of 8
+    const u16 *zero;                // >= 256 zero bytes
+};
+__device__ __forceinline__ int cl_keyb(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+constexpr int CLW_KPX = 64;                        // pixels per reduction step
+__global__ void __launch_bounds__(256, 2)
+cl_wgrad_kernel(const u16 *__restrict__ dY, const u16 *__restrict__ Xc, float *__restrict__ part, const ClWgArgs g) {
+    constexpr int ABYTES = 128 * 128, BBYTES = 64 * 256, BUF = ABYTES + BBYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char cl_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    // Workgroups go to the 8 XCDs round-robin by their linear id, and each XCD has its own L2: XCD x is given a CONTIGUOUS eighth of the
+    // (tile, split) list, tiles ordered (column block, row block, tap) with the splits of one tile adjacent, so that the workgroups of one
+    // XCD share dY rows (same row block) and input planes (same column block) instead of every L2 fetching every operand.
+    uint32_t L = blockIdx.x;
+    if (L < g.total8) L = (L & 7u) * (g.total8 >> 3) + (L >> 3);
+    const uint32_t tile = fd_div(L, g.fdS), split = L - tile * g.splits;
+    const uint32_t tc = fd_div(tile, g.fd9), t = tile - tc * 9u;
+    const uint32_t ct = fd_div(tc, g.fdM);
+    const int m0 = (int)(tc - ct * g.mtiles) * 128, c0 = (int)ct * 128;
+    const int r_beg = (int)split * g.rlen, r_end = min(g.rtiles, r_beg + g.rlen);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    // A pieces: p = tid + 256 u -> row p >> 3 (dY channel), chunk p & 7 (8 pixels); B pieces: p -> pixel row p >> 4, chunk p & 15 (8 channels).
+    // Addresses are kept incremental: a reduction tile starts 64 pixels after the one before it (or at pixel 0 of the next image), so the
+    // per-thread parts are constants (A) or advance by a constant step with one carry (B); the image / tile origin is wave-uniform.
+    const int arow = tid >> 3, achunk = tid & 7;
+    const int brow = tid >> 4, bchunk = tid & 15;
+    uint32_t aoff[4];
+    int alim[4];                                   // the piece holds pixels of the plane while p0 < alim
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int row = arow + 32 * u, sc = achunk ^ cl_key(row);  // LDS chunk achunk of the row holds source chunk sc
+        aoff[u] = (uint32_t)(((m0 + row) * g.P + sc * 8) * 2);
+        alim[u] = g.P - sc * 8;
+    }
+    const uint32_t q64 = fd_div(64u, g.fdGW), r64 = 64u - q64 * g.GW;  // 64 pixels further = q64 rows and r64 columns further
+    const uint32_t rowb = (uint32_t)g.Wp * g.C * 2u, colb = (uint32_t)g.C * 2u;
+    uint32_t boff0[4], bx0[4], boff[4], bx[4];
+    const uint32_t tdelta = g.tap_delta[t] + (uint32_t)c0 * 2u;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int row = brow + 16 * u, sc = bchunk ^ cl_keyb(row);
+        const uint32_t y = fd_div((uint32_t)row, g.fdGW), xx = (uint32_t)row - y * g.GW;     // pixel `row` of an image (tile 0)
+        boff0[u] = y * rowb + xx * colb + tdelta + (uint32_t)(sc * 16);
+        bx0[u] = xx;
+    }
+    int ld_r = r_beg;
+    uint32_t ld_n = fd_div((uint32_t)r_beg, g.fdPt);
+    int ld_p0 = (r_beg - (int)ld_n * g.ptiles) * 64;
+#pragma unroll
+    for (int u = 0; u < 4; u++) { // state of the first tile of this split: pixel ld_p0 + row
+        const int row = brow + 16 * u, sc = bchunk ^ cl_keyb(row);
+        const uint32_t pp = (uint32_t)(ld_p0 + row);
+        const uint32_t y = fd_div(pp, g.fdGW), xx = pp - y * g.GW;
+        boff[u] = y * rowb + xx * colb + tdelta + (uint32_t)(sc * 16);
+        bx[u] = xx;
+    }
+    const int tin0 = ld_p0 >> 6;
+    auto issue = [&](const int buf) {
+        const unsigned char *fa = (const unsigned char *)dY + ((size_t)ld_n * g.K * g.P + ld_p0) * 2;        // wave-uniform
+        const unsigned char *fb = (const unsigned char *)Xc + (size_t)ld_n * g.img_rows * rowb;                // wave-uniform
+        unsigned char *la = cl_smem + buf * BUF + wave * 1024, *lb = cl_smem + buf * BUF + ABYTES + wave * 1024;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const unsigned char *src = ld_p0 < alim[u] ? fa + aoff[u] : (const unsigned char *)g.zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(la + u * 4096), 16, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const unsigned char *src = ld_p0 + brow + 16 * u < g.P ? fb + boff[u] : (const unsigned char *)g.zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(lb + u * 4096), 16, 0, 0);
+        }
+        // the next tile: 64 pixels on, or pixel 0 of the next image
+        ld_r++;
+        ld_p0 += 64;
+        if (ld_p0 >= g.ptiles * 64) {
+            ld_p0 = 0; ld_n++;
+#pragma unroll
+            for (int u = 0; u < 4; u++) { boff[u] = boff0[u]; bx[u] = bx0[u]; }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                uint32_t nx = bx[u] + r64;
+                const uint32_t carry = nx >= (uint32_t)g.GW ? 1u : 0u;
+                nx -= carry * (uint32_t)g.GW;
+                boff[u] += (q64 + carry) * rowb + (nx - bx[u]) * colb;   // (unsigned wrap-around is the subtraction it stands for)
+                bx[u] = nx;
+            }
+        }
+    };
+    const int fr = lane & 31, fk = lane >> 5;
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tcb = (lane >> 4) & 1; // transposed read: row within the 4-row block, column quad, 16-column half
+    auto compute_n = [&](const int buf, const int nsub, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const unsigned char *as = cl_smem + buf * BUF, *bs = as + ABYTES;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            if (!FULL && s >= nsub) break;
+            bf16x8 av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int row = wm * 64 + i * 32 + fr;
+                av[i] = *(const bf16x8 *)(as + row * 128 + (((2 * s + fk) ^ cl_key(row)) * 16));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int ch0 = (wn * 64 + j * 32) / 8 + 2 * tcb + (tp >> 1); // 16-byte chunk of the image row this lane addresses
+                cl_s16x4 lo, hi;
+                {
+                    const int row = 16 * s + 8 * fk + tq;
+                    lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) cl_s16x4 *)(bs + row * 256 + ((ch0 ^ cl_keyb(row)) * 16) + 8 * (tp & 1)));
+                }
+                {
+                    const int row = 16 * s + 8 * fk + 4 + tq;
+                    hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) cl_s16x4 *)(bs + row * 256 + ((ch0 ^ cl_keyb(row)) * 16) + 8 * (tp & 1)));
+                }
+                typedef short s16x8 __attribute__((ext_vector_type(8)));
+                s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                bv[j] = *(bf16x8 *)&v;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    // full tiles run in an inner loop of their own (one code path: the accumulators stay where they are); the partial tail tile of an
+    // image, whose 16-pixel sub-steps past the end of the plane are all zeros, multiplies only the sub-steps that hold pixels.
+    // (Measured and dropped: 32-pixel steps in four LDS stages with counted vmcnt waits and no drain -- 8 % slower, the extra barriers
+    // cost more than the deeper prefetch returns.)
+    if (r_beg < r_end) {
+        issue(0);
+        const int full = g.P >> 6, tail_sub = ((g.P & 63) + 15) >> 4;
+        int it = r_beg, tin = tin0;
+        while (it < r_end) {
+            const int nf = min(r_end - it, full - tin);
+            for (int k = 0; k < nf; k++, it++) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (it + 1 < r_end) issue((it + 1 - r_beg) & 1);
+                compute_n((it - r_beg) & 1, 4, std::true_type{});
+            }
+            tin += max(nf, 0);
+            if (it < r_end && tin == full && g.ptiles > full) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (it + 1 < r_end) issue((it + 1 - r_beg) & 1);
+                compute_n((it - r_beg) & 1, tail_sub, std::false_type{});
+                it++; tin++;
+            }
+            if (tin >= g.ptiles) tin = 0;
+        }
+    }
+    // partials [split][t][k][c]: accumulator (i, j): column = c0 + wn 64 + j 32 + (lane & 31), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    float *o = part + ((size_t)((size_t)split * 9 + t) * g.K) * g.C + c0 + wn * 64 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                o[(size_t)(m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * g.C + j * 32] = acc[i][j][r];
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 static int cl_launch(hipStream_t st, const u16 *A, const u16 *In, u16 *Out, ClArgs &g, int N, double flops, double bytes) {
     g.ncols = N * g.P;
@@ -609,6 +804,73 @@ int mid_cl_dgrad2(mid_stream s, const void *dyp, const void *a_tiles, void *dx, 
     hipLaunchKernelGGL(cl_dgrad2_kernel, dim3(g.tiles, 2), dim3(256), 65536, st, (const u16 *)a_tiles, (const u16 *)dyp, (u16 *)dx, g);
     mi_prof_end(st);
     MI_LAUNCH_CHECK("cl_dgrad2_kernel");
+    return 0;
+}
+static void *g_cl_zero = nullptr;
+static int cl_wgrad_splits(int N, int C, int K, int P) {
+    const long tiles = (long)(K / 128) * (C / 128) * 9, rt = (long)N * ((P + CLW_KPX - 1) / CLW_KPX);
+    int best = 1;
+    double best_eff = 0;
+    for (int sp = 1; sp <= 256; sp++) {
+        if (sp > 1 && rt / sp < 24) break;
+        const double waves = (double)tiles * sp / 512.0;
+        const double eff = waves / (double)((long)((tiles * sp + 511) / 512));
+        if (eff > best_eff + 0.02) { best_eff = eff; best = sp; }
+    }
+    return best;
+}
+/* weight gradient on the channel-last input: 3x3, stride 1 or 2; C % 128, K % 128, output planes a multiple of 4 pixels */
+int mid_cl_wgrad_supported(int N, int C, int H, int K, int stride) {
+    if (!mid_cl_supported(0, N, C, H, K, stride)) return 0;
+    const int P = (H / stride) * (H / stride);
+    return C % 128 == 0 && K % 128 == 0 && P % 4 == 0;
+}
+size_t mid_cl_wgrad_part_floats(int N, int C, int H, int K, int stride) {
+    const int P = (H / stride) * (H / stride);
+    return (size_t)cl_wgrad_splits(N, C, K, P) * 9 * K * C;
+}
+/* dw (fp32 KCRS) from dy (bf16 NCHW, K channels, H/stride planes) and xp = the forward's re-laid input (mid_cl_relayout); part: scratch of
+ * mid_cl_wgrad_part_floats floats */
+int mid_cl_wgrad(mid_stream s, const void *xp, const void *dy, float *dw, float *part, size_t part_floats, int N, int C, int H, int K, int stride) {
+    hipStream_t st = (hipStream_t)s;
+    if (!mid_cl_wgrad_supported(N, C, H, K, stride)) { mi_record_error("mid_cl_wgrad", "shape not covered"); return -2; }
+    if (!g_cl_zero) {
+        if (hipMalloc(&g_cl_zero, 512) != hipSuccess) { mi_record_error("mid_cl_wgrad", "zero page"); return -1; }
+        (void)hipMemsetAsync(g_cl_zero, 0, 512, st);
+    }
+    ClWgArgs g = {};
+    g.K = K; g.C = C; g.GW = H / stride; g.P = g.GW * g.GW;
+    if (stride == 2) {
+        const int Hp = g.GW + 1;
+        g.img_rows = 4 * Hp; g.Wp = Hp;
+        for (int t = 0; t < 9; t++) {
+            const int r = t / 3, sx = t % 3, q = 2 * ((r + 1) & 1) + ((sx + 1) & 1);
+            g.tap_delta[t] = (uint32_t)(((q * Hp + (r > 0)) * Hp + (sx > 0)) * C) * 2u;
+        }
+    } else {
+        g.img_rows = H + 2; g.Wp = H + 2;
+        for (int t = 0; t < 9; t++) g.tap_delta[t] = (uint32_t)(((t / 3) * g.Wp + (t % 3)) * C) * 2u;
+    }
+    g.ptiles = (g.P + CLW_KPX - 1) / CLW_KPX; g.rtiles = N * g.ptiles;
+    const int splits = cl_wgrad_splits(N, C, K, g.P);
+    if (part_floats < (size_t)splits * 9 * K * C) { mi_record_error("mid_cl_wgrad", "workspace too small"); return -3; }
+    g.rlen = mi_cdiv(g.rtiles, splits);
+    const int used = mi_cdiv(g.rtiles, g.rlen);
+    g.ctiles = C / 128; g.mtiles = K / 128;
+    g.fdGW = make_fastdiv(g.GW); g.fdPt = make_fastdiv(g.ptiles); g.fdM = make_fastdiv(g.mtiles); g.fdS = make_fastdiv(used); g.fd9 = make_fastdiv(9);
+    g.splits = (uint32_t)used; g.total8 = (uint32_t)(g.mtiles * g.ctiles * 9 * used) & ~7u;
+    g.zero = (const u16 *)g_cl_zero;
+    static int attr_set = 0;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)cl_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess) { mi_record_error("cl_wgrad_kernel", "cannot raise the dynamic LDS limit"); return -1; }
+        attr_set = 1;
+    }
+    mi_prof_begin(st, MI_FAM_PCONV, 2.0 * 9 * (double)N * g.P * C * K, 2.0 * ((double)N * C * H * H + (double)N * g.P * K) + 4.0 * 9 * C * K);
+    hipLaunchKernelGGL(cl_wgrad_kernel, dim3(g.mtiles * g.ctiles * 9 * used), dim3(256), 65536, st, (const u16 *)dy, (const u16 *)xp, part, g);
+    const int rr = mi_igemm_wgrad_reduce(st, part, dw, K, C, 3, used);
+    mi_prof_end(st);
+    if (rr) return rr;
+    MI_LAUNCH_CHECK("cl_wgrad_kernel");
     return 0;
 }
 /* y (bf16 NCHW) = conv3x3 (stride 1 or 2, pad 1) of the re-laid input xp with a_tiles = the forward k-step tiles [t][c/64][K][64]

@@ -147,6 +147,10 @@ size_t mid_cl_operand_bytes(int op, int N, int C, int H, int K, int stride);
 int mid_cl_relayout(mid_stream s, const void *x, void *xp, int N, int C, int H, int parity);
 int mid_cl_fwd(mid_stream s, const void *xp, const void *a_tiles, void *y, int N, int C, int H, int K, int stride, mid_bn_parts *parts);
 int mid_cl_dgrad(mid_stream s, const void *dyp, const void *a_tiles, void *dx, const void *addend, int N, int C, int H, int K);
+/* weight gradient from dY (NCHW) and the forward's re-laid input: transposed LDS reads on the pixel-major operand */
+int mid_cl_wgrad_supported(int N, int C, int H, int K, int stride);
+size_t mid_cl_wgrad_part_floats(int N, int C, int H, int K, int stride);
+int mid_cl_wgrad(mid_stream s, const void *xp, const void *dy, float *dw, float *part, size_t part_floats, int N, int C, int H, int K, int stride);
 /* stride-2 dgrad: dY (K channels, H/2 x H/2) re-laid channel-last with one zero row / column at the far end, both column parities of dx in
  * one workgroup (dense stores) */
 int mid_cl_dgrad2_supported(int N, int C, int H, int K);

@@ -49,6 +49,7 @@ typedef struct {
     /* the stride-2 dgrads' output gradient re-laid channel-last with a zero row / column at the far end (kernels_cl_bf16.hip); the
      * halo is zeroed once, when the buffers are made; NULL = that layer's dgrad stays on the NCHW kernel */
     void *dye_spatial, *dye_proj;
+    void *cl_spatial, *cl_proj;  /* channel-last parity planes of the layer's input: forward + weight gradient (kernels_cl_bf16.hip) */
 } MiParity;
 typedef struct MiCtx {
     mid_workspace ws;
@@ -87,6 +88,7 @@ typedef struct MiCtx {
     int params_dirty;            /* update_parameters ran since the last weight re-layout */
     unsigned long host_epoch_seen; /* the process-wide host-write count (mi_copy_to_device) that re-layout was made at */
     void *cur_par; size_t cur_par_bytes; int *cur_par_valid; /* parity buffer of the stride-2 convolution about to be launched */
+    void *cur_cl;                /* ... its channel-last parity planes (the forward pass fills them, the weight gradient reads them), or NULL */
     void *cur_dye;               /* ... and the channel-last buffer for its output gradient (stride-2 dgrad), or NULL */
     char *dump_root;
     /* every device allocation of this trainer (freed by destroy_trainer) */

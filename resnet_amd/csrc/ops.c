@@ -360,3 +360,18 @@ int mi_op_conv_dgrad_bf16_cl(const float *w, const void *dy, void *dx, int N, in
     mid_free(dyp); mid_free(at);
     return rc;
 }
+
+int mi_op_conv_wgrad_bf16_cl(const void *x, const void *dy, float *dw, int N, int C, int H, int K, int stride) {
+    if (!mid_cl_wgrad_supported(N, C, H, K, stride)) return -2;
+    mid_stream st = mi_global()->compute;
+    const size_t xb = mid_cl_operand_bytes(0, N, C, H, K, stride), pf = mid_cl_wgrad_part_floats(N, C, H, K, stride);
+    void *xp = mid_malloc(xb);
+    float *part = (float *)mid_malloc(pf * sizeof(float));
+    if (!xp || !part) { mid_free(xp); mid_free(part); return -3; }
+    mid_memset(xp, 0, xb, st);
+    int rc = mid_cl_relayout(st, x, xp, N, C, H, stride == 2);
+    if (!rc) rc = mid_cl_wgrad(st, xp, dy, dw, part, pf, N, C, H, K, stride);
+    rc = finish(rc);
+    mid_free(xp); mid_free(part);
+    return rc;
+}

@@ -340,6 +340,7 @@ static void size_workspaces(MiCtx *c, const Dims *d, ConvBlock **blocks, int N) 
     do {                                                                                      \
         size_t a_ = mid_conv_ws_wt_floats(C_, K_, k_), b_ = mid_conv_ws_part_floats(N, C_, H_, K_, k_, s_); \
         if (c->dtype == MID_BF16 && (k_) <= 3) { size_t e_ = mid_bf16_part_floats(N, C_, H_, K_, k_, s_); if (e_ > b_) b_ = e_; } \
+        if (c->dtype == MID_BF16 && (k_) == 3 && mid_cl_wgrad_supported(N, C_, H_, K_, s_)) { size_t e_ = mid_cl_wgrad_part_floats(N, C_, H_, K_, s_); if (e_ > b_) b_ = e_; } \
         if (a_ > wt) wt = a_;                                                                 \
         if (b_ > part) part = b_;                                                             \
         if ((K_) > maxc) maxc = (K_);                                                         \
@@ -367,6 +368,19 @@ static void size_workspaces(MiCtx *c, const Dims *d, ConvBlock **blocks, int N) 
             c->par[i].spatial_bytes = e1 * 2;
             c->par[i].spatial = (char *)mi_ctx_alloc(c, e1 * 2 + 2 * MI_GUARD) + MI_GUARD;
             if (b->projection) { c->par[i].proj_bytes = e2 * 2; c->par[i].proj = (char *)mi_ctx_alloc(c, e2 * 2 + 2 * MI_GUARD) + MI_GUARD; }
+            /* forward and weight gradient on channel-last parity planes (RESNET_MI_BF16_CL_S2=0: the NCHW kernels and their planes) */
+            if (!(getenv("RESNET_MI_BF16_CL_S2") && atoi(getenv("RESNET_MI_BF16_CL_S2")) == 0)) {
+                if (mid_cl_supported(0, N, b->reduced_depth, (int)H, b->reduced_depth, 2)) {
+                    const size_t by = mid_cl_operand_bytes(0, N, b->reduced_depth, (int)H, b->reduced_depth, 2);
+                    c->par[i].cl_spatial = mi_ctx_alloc(c, by);
+                    mid_memset(c->par[i].cl_spatial, 0, by, G.compute); /* the halo stays zero: the re-layout writes the interior only */
+                }
+                if (b->projection && mid_cl_supported(0, N, b->incoming_filters, (int)H, b->expanded_depth, 2)) {
+                    const size_t by = mid_cl_operand_bytes(0, N, b->incoming_filters, (int)H, b->expanded_depth, 2);
+                    c->par[i].cl_proj = mi_ctx_alloc(c, by);
+                    mid_memset(c->par[i].cl_proj, 0, by, G.compute);
+                }
+            }
             /* the stride-2 dgrads on channel-last dY (RESNET_MI_BF16_CL_DGRAD2=0: the NCHW kernel's four parity classes) */
             if (!(getenv("RESNET_MI_BF16_CL_DGRAD2") && atoi(getenv("RESNET_MI_BF16_CL_DGRAD2")) == 0)) {
                 if (mid_cl_dgrad2_supported(N, b->reduced_depth, (int)H, b->reduced_depth)) {
@@ -759,7 +773,7 @@ void mi_trainer_poll_errors(Train_ResNet *t) {
  * stem: the 7x7 convolution keeps fp32 input / output in every storage type; only its BN output is an activation tensor */
 /* c->cur_par: parity copy of the NEXT stride-2 convolution's input (set by the caller); c->cur_par_valid: where the forward pass
  * records whether it really wrote the planes (it does only on the 16-byte staging route), read back by the weight gradient */
-static void set_cur_par(MiCtx *c, void *buf, size_t bytes, int *valid) { c->cur_par = buf; c->cur_par_bytes = bytes; c->cur_par_valid = valid; c->cur_dye = NULL; }
+static void set_cur_par(MiCtx *c, void *buf, size_t bytes, int *valid) { c->cur_par = buf; c->cur_par_bytes = bytes; c->cur_par_valid = valid; c->cur_dye = NULL; c->cur_cl = NULL; }
 static void unit_fwd(Train_ResNet *t, const float *in, const float *w, const BatchNorm *bn, Cache_BatchNorm *cache,
                      float *conv_out, float *act_out, const float *residual, int C, int H, int K, int k, int stride,
                      int relu, int stem) {
@@ -778,6 +792,11 @@ static void unit_fwd(Train_ResNet *t, const float *in, const float *w, const Bat
         parts = &c->bn_parts; /* (the stem's tensors are fp32 here, but its statistics still come from the kernel's accumulators) */
         ck(mid_stem_fwd_bf16(G.compute, in, w, conv_out, c->stem_xp, c->stem_xp_bytes, c->stem_scratch, c->stem_scratch_floats, N, H, parts),
            "stem convolution forward (bf16 operands)");
+    } else if (bf && k == 3 && stride == 2 && c->cur_cl && we && we->fwd) {
+        /* channel-last route: the input re-laid once as four zero-padded parity planes, which the weight gradient reads again */
+        ck(mid_cl_relayout(G.compute, in, c->cur_cl, N, C, H, 1), "input re-layout (channel-last parity planes)");
+        ck(mid_cl_fwd(G.compute, c->cur_cl, we->fwd, conv_out, N, C, H, K, 2, parts), "convolution forward (bf16, channel-last)");
+        if (c->cur_par_valid) *c->cur_par_valid = 0;
     } else if (bf) {
         ck(mid_conv_fwd_bf16(G.compute, &c->ws, in, w, conv_out, N, C, H, K, k, stride, parts), "convolution forward (bf16)");
         if (stride == 2 && c->cur_par_valid) *c->cur_par_valid = c->ws.s2d_valid; /* the launch says whether it left the parity planes */
@@ -818,11 +837,13 @@ void forward_pass(Train_ResNet *t) {
         unit_fwd(t, bin, b->depth_reduction, b->norm_depth_reduction, k->norm_post_reduced, k->post_reduced,
                  k->post_reduced_activated, NULL, b->incoming_filters, H, b->reduced_depth, 1, 1, 1, 0);
         if (c->par) set_cur_par(c, c->par[i].spatial, c->par[i].spatial_bytes, &c->par[i].spatial_valid); else set_cur_par(c, NULL, 0, NULL);
+        c->cur_cl = c->par ? c->par[i].cl_spatial : NULL;
         unit_fwd(t, k->post_reduced_activated, b->spatial, b->norm_spatial, k->norm_post_spatial, k->post_spatial,
                  k->post_spatial_activated, NULL, b->reduced_depth, H, b->reduced_depth, 3, b->stride, 1, 0);
         const float *res = bin;
         if (b->projection) { /* resnet.cu:1685-1704 */
             if (c->par) set_cur_par(c, c->par[i].proj, c->par[i].proj_bytes, &c->par[i].proj_valid); else set_cur_par(c, NULL, 0, NULL);
+            c->cur_cl = c->par ? c->par[i].cl_proj : NULL;
             unit_fwd(t, bin, b->projection, b->norm_projection, k->norm_post_projection, k->transformed_residual,
                      k->post_projection_norm_vals, NULL, b->incoming_filters, H, b->expanded_depth, b->stride == 2 ? 3 : 1,
                      b->stride, 0, 0);
@@ -917,6 +938,8 @@ static void conv_wgrad_t(Train_ResNet *t, mid_stream st, const float *x, const f
         ck(mid_stem_wgrad_f32(st, c->stem_xp, dy, dw, c->stem_scratch, c->stem_scratch_floats, t->batch_size, H), "stem convolution wgrad (fp32 matrix cores)");
     else if (stem && c->stem_scratch) /* the forward pass left the batch as padded bf16 parity planes */
         ck(mid_stem_wgrad_bf16(st, c->stem_xp, dy, dw, c->stem_scratch, c->stem_scratch_floats, t->batch_size, H), "stem convolution wgrad (bf16 operands)");
+    else if (c->dtype == MID_BF16 && !stem && k == 3 && stride == 2 && c->cur_cl && mid_cl_wgrad_supported(t->batch_size, C, H, K, 2))
+        ck(mid_cl_wgrad(st, c->cur_cl, dy, dw, c->ws.part, c->ws.part_floats, t->batch_size, C, H, K, 2), "convolution wgrad (bf16, channel-last)");
     else if (c->dtype == MID_BF16 && !stem) ck(mid_conv_wgrad_bf16(st, &c->ws, x, dy, dw, t->batch_size, C, H, K, k, stride), "convolution wgrad (bf16)");
     else ck(mid_conv_wgrad(st, &c->ws, x, dy, dw, t->batch_size, C, H, K, k, stride), "convolution wgrad");
 }
@@ -1014,6 +1037,7 @@ void backwards_pass(Train_ResNet *t) {
              * pass also leaves relu'(out) * up in dk->output, which the expansion BN' then reads instead of up + mask */
             if (c->par) set_cur_par(c, c->par[i].proj, c->par[i].proj_bytes, &c->par[i].proj_valid); else set_cur_par(c, NULL, 0, NULL);
             c->cur_dye = c->par ? c->par[i].dye_proj : NULL;
+            c->cur_cl = c->par ? c->par[i].cl_proj : NULL;
             unit_bwd(t, bin, b->projection, b->norm_projection, k->norm_post_projection, db->norm_projection,
                      k->transformed_residual, up, k->output_activated, 3, dk->output, dk->transformed_residual, s_proj, dbin, NULL,
                      db->projection, b->incoming_filters, H, b->expanded_depth, b->stride == 2 ? 3 : 1, b->stride, 0);
@@ -1041,6 +1065,7 @@ void backwards_pass(Train_ResNet *t) {
                               H * H, t->eps, 1), "BN recompute");
         if (c->par) set_cur_par(c, c->par[i].spatial, c->par[i].spatial_bytes, &c->par[i].spatial_valid); else set_cur_par(c, NULL, 0, NULL);
         c->cur_dye = c->par ? c->par[i].dye_spatial : NULL;
+        c->cur_cl = c->par ? c->par[i].cl_spatial : NULL;
         FZ_REQ(2, k->post_reduced, k->post_reduced_activated, k->norm_post_reduced->means); /* spatial dgrad -> reduction BN' */
         unit_bwd(t, k->post_reduced_activated, b->spatial, b->norm_spatial, k->norm_post_spatial, db->norm_spatial,
                  k->post_spatial, dk->post_spatial_activated, NULL, 1, NULL, dk->post_spatial, s_spa, dk->post_reduced_activated, NULL,

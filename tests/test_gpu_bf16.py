@@ -630,3 +630,19 @@ def test_conv_dgrad_s2_bf16_channel_last(ops, oracle, shape):
     ref = oracle.conv_dgrad(w, dy, H, 2)
     got = ops.conv_dgrad_bf16_cl(w, nchw(dy), H, stride=2)
     check_bf(nhwc(got), ref, "channel-last conv dgrad s2 %s" % (shape,))
+
+
+CL_WG_SHAPES = [(128, 56, 128, 2, 2), (256, 56, 512, 2, 1), (256, 28, 256, 2, 3), (512, 28, 1024, 2, 2), (128, 28, 128, 1, 3), (256, 14, 256, 1, 3), (128, 8, 128, 1, 4), (128, 8, 256, 2, 5),
+                (128, 10, 128, 1, 3)]
+
+
+@pytest.mark.parametrize("shape", CL_WG_SHAPES, ids=["C%d_H%d_K%d_s%d_N%d" % s for s in CL_WG_SHAPES])
+def test_conv_wgrad_bf16_channel_last(ops, oracle, shape):
+    """weight gradient from dY (NCHW) and the channel-last input: transposed LDS reads (ds_read_b64_tr_b16) on the pixel-major operand, ragged
+    64-pixel reduction tiles (planes of 784, 196, 100, 64, 16 pixels) padded with a zero page"""
+    C, H, K, stride, N = shape
+    x = bf16_round(rand((N, H, H, C), 7))
+    dy = bf16_round(rand((N, H // stride, H // stride, K), 9))
+    ref = oracle.conv_wgrad(x, dy, 3, stride)
+    got = ops.conv_wgrad_bf16_cl(nchw(x), nchw(dy), stride)
+    check_grad(got, ref, "channel-last conv wgrad %s" % (shape,))

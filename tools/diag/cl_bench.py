@@ -13,7 +13,9 @@ def fam_ms():
         n_, ms_, fl_, by_ = C.c_long(0), C.c_double(0), C.c_double(0), C.c_double(0)
         L.mi_prof_get(fam, C.byref(n_), C.byref(ms_), C.byref(fl_), C.byref(by_)); ms += ms_.value
     return ms
+ONLY = sys.argv[2].split(",") if len(sys.argv) > 2 else None
 for name, Cc, H, K, S in LAY:
+    if ONLY and name not in ONLY: continue
     Ho = H // S
     nx, nw, ny = N * Cc * H * H, K * Cc * 9, N * K * Ho * Ho
     x, w, y = (L.mi_malloc(4 * n) for n in (nx, nw, ny))
@@ -28,6 +30,10 @@ for name, Cc, H, K, S in LAY:
         ops_ += [("dgrad nchw", lambda: L.mi_op_conv_dgrad_bf16(w, yb, xb, N, Cc, H, K, 3, 1, 0)), ("dgrad cl", lambda: L.mi_op_conv_dgrad_bf16_cl(w, yb, xb, N, Cc, H, K, 1, 0))]
     else:
         ops_ += [("dgrad nchw", lambda: L.mi_op_conv_dgrad_bf16(w, yb, xb, N, Cc, H, K, 3, 2, 0)), ("dgrad cl", lambda: L.mi_op_conv_dgrad_bf16_cl(w, yb, xb, N, Cc, H, K, 2, 0))]
+    dw = L.mi_malloc(4 * nw)
+    ops_ += [("wgrad nchw", lambda: L.mi_op_conv_wgrad_bf16(xb, yb, dw, N, Cc, H, K, 3, S))]
+    if Cc % 128 == 0 and K % 128 == 0 and (Ho * Ho) % 4 == 0:
+        ops_ += [("wgrad cl", lambda: L.mi_op_conv_wgrad_bf16_cl(xb, yb, dw, N, Cc, H, K, S))]
     for which, fn in ops_:
         L.mi_prof_enable(1)
         for rep in range(4):
@@ -37,4 +43,5 @@ for name, Cc, H, K, S in LAY:
         ms = fam_ms() / 3; L.mi_prof_enable(0)
         out.append("%s %.3f ms %.0f TF/s" % (which, ms, flops / ms / 1e9))
     print("%-10s" % name, " | ".join(out), flush=True)
+    L.mi_free(dw)
     for p in (x, w, y, xb, yb): L.mi_free(p)
