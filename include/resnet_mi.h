@@ -384,6 +384,7 @@ void mi_batch_set_rank_slice(Batch *b, int rank, int world);
  * (y, residual, dy, mask_src, gated_out).  Supported pairs: (F32,F32), (BF16,BF16), (F32,BF16). */
 int mi_op_convert(const void *in, int in_dt, void *out, int out_dt, size_t n);
 int mi_bf16_conv_supported(int op, int N, int C, int H, int K, int k, int stride); /* op 0 fwd, 1 dgrad, 2 wgrad */
+int mi_bf16_pw_wgrad_supported(int N, int C, int H, int K); /* 1: this 1x1 weight gradient runs on the LDS-DMA kernel (both operands as they lie) */
 int mi_op_conv_fwd_bf16(const void *x_bf16, const float *w_kcrs, void *y_bf16, int N, int C, int H, int K, int k, int stride);
 int mi_op_conv_dgrad_bf16(const float *w_kcrs, const void *dy_bf16, void *dx_bf16, int N, int C, int H, int K, int k, int stride,
                           int to_add);

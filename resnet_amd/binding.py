@@ -190,6 +190,7 @@ PROTOTYPES = {
     "mi_batch_set_rank_slice": (None, [_B, _i, _i]),
     "mi_op_convert": (_i, [_vp, _i, _vp, _i, _sz]),
     "mi_bf16_conv_supported": (_i, [_i] * 7),
+    "mi_bf16_pw_wgrad_supported": (_i, [_i] * 4),
     "mi_op_conv_fwd_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     "mi_op_conv_dgrad_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
     "mi_op_conv_wgrad_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),

@@ -529,8 +529,8 @@ struct ClWgArgs {
     int rlen;                       // reduction tiles per split
     int ctiles, mtiles;             // C / 128, K / 128
     uint32_t tap_delta[9];
-    FastDiv fdGW, fdPt, fdM, fdS, fd9;
-    uint32_t splits, total8;        // splits in use; (tiles * splits) rounded down to a multiple of 8
+    FastDiv fdGW, fdPt, fdM, fdT, fd9;
+    uint32_t tiles, total8;         // output tiles (with taps); (tiles * splits) rounded down to a multiple of 8
     const u16 *zero;                // >= 256 zero bytes
 };
 __device__ __forceinline__ int cl_keyb(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -543,11 +543,11 @@ cl_wgrad_kernel(const u16 *__restrict__ dY, const u16 *__restrict__ Xc, float *_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     // Workgroups go to the 8 XCDs round-robin by their linear id, and each XCD has its own L2: XCD x is given a CONTIGUOUS eighth of the
-    // (tile, split) list, tiles ordered (column block, row block, tap) with the splits of one tile adjacent, so that the workgroups of one
-    // XCD share dY rows (same row block) and input planes (same column block) instead of every L2 fetching every operand.
+    // (split, tile) list, tiles (column block, row block, tap) fastest, so that all the tiles that read one stretch of pixels run on one
+    // XCD at about the same time and each operand byte is fetched from HBM by one L2.
     uint32_t L = blockIdx.x;
     if (L < g.total8) L = (L & 7u) * (g.total8 >> 3) + (L >> 3);
-    const uint32_t tile = fd_div(L, g.fdS), split = L - tile * g.splits;
+    const uint32_t split = fd_div(L, g.fdT), tile = L - split * g.tiles;
     const uint32_t tc = fd_div(tile, g.fd9), t = tile - tc * 9u;
     const uint32_t ct = fd_div(tc, g.fdM);
     const int m0 = (int)(tc - ct * g.mtiles) * 128, c0 = (int)ct * 128;
@@ -696,6 +696,141 @@ cl_wgrad_kernel(const u16 *__restrict__ dY, const u16 *__restrict__ Xc, float *_
     }
     // partials [split][t][k][c]: accumulator (i, j): column = c0 + wn 64 + j 32 + (lane & 31), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     float *o = part + ((size_t)((size_t)split * 9 + t) * g.K) * g.C + c0 + wn * 64 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                o[(size_t)(m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * g.C + j * 32] = acc[i][j][r];
+}
+
+// Weight gradient of a 1x1 convolution, both operands as they lie (bf16 NCHW):  dW[k][c] = sum over images and pixels dY[n][k][p] * X[n][c][p].
+// The reduction index (pixels) is the contiguous one of BOTH operands, so both stage by LDS-DMA into [128 channels][64 pixels] images of
+// 128-byte rows (XOR-swizzled 16-byte chunks) and both fragments are plain ds_read_b128.  Tiles, splits, XCD placement and the two-stage
+// fixed-order sum as cl_wgrad_kernel.  A plane that is not a multiple of 8 pixels (P % 8 == 4) ends in a chunk of 4 pixels: that chunk is
+// loaded 4 pixels EARLY on both sides (pixels P-8 .. P-1: nothing is read past a row, so nothing past the tensors), and the dY fragment that
+// holds it has its first four elements -- pixels already counted by the chunk before -- set to zero.
+struct PwWgArgs {
+    int K, C, P;
+    int ptiles, rtiles, rlen;       // 64-pixel tiles per image; reduction tiles in all = N * ptiles; per split
+    int mtiles;                     // K / 128
+    FastDiv fdPt, fdM, fdT;
+    uint32_t tiles, total8;         // output tiles; (tiles * splits) rounded down to a multiple of 8
+    const u16 *zero;                // >= 256 zero bytes
+};
+__global__ void __launch_bounds__(256, 2)
+pw_wgrad_kernel(const u16 *__restrict__ dY, const u16 *__restrict__ X, float *__restrict__ part, const PwWgArgs g) {
+    constexpr int ABYTES = 128 * 128, BUF = 2 * ABYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char cl_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    // Workgroups go to the 8 XCDs round-robin by their linear id, and each XCD has its own L2: XCD x is given a CONTIGUOUS eighth of the
+    // (split, tile) list, tiles fastest, so that all the tiles that read one stretch of pixels run on one XCD at about the same time and
+    // each operand byte is fetched from HBM by one L2, once (tile-fastest over round-robin XCDs fetched the narrower operand C/128 times)
+    uint32_t L = blockIdx.x;
+    if (L < g.total8) L = (L & 7u) * (g.total8 >> 3) + (L >> 3);
+    const uint32_t split = fd_div(L, g.fdT), tile = L - split * g.tiles;
+    const uint32_t ct = fd_div(tile, g.fdM);
+    const int m0 = (int)(tile - ct * g.mtiles) * 128, c0 = (int)ct * 128;
+    const int r_beg = (int)split * g.rlen, r_end = min(g.rtiles, r_beg + g.rlen);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    // pieces of 16 bytes: p = tid + 256 u -> LDS row p >> 3 (channel), LDS chunk p & 7, which holds source chunk sc = chunk ^ key (8 pixels)
+    const int arow = tid >> 3, achunk = tid & 7;
+    const int rem8 = g.P & 7;
+    uint32_t aoff[4], boff[4];
+    int scx[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int row = arow + 32 * u, sc = achunk ^ cl_key(row);
+        aoff[u] = (uint32_t)(((m0 + row) * g.P + sc * 8) * 2);
+        boff[u] = (uint32_t)(((c0 + row) * g.P + sc * 8) * 2);
+        scx[u] = sc * 8;
+    }
+    int ld_r = r_beg;
+    uint32_t ld_n = fd_div((uint32_t)r_beg, g.fdPt);
+    int ld_p0 = (r_beg - (int)ld_n * g.ptiles) * 64;
+    const int tin0 = ld_p0 >> 6;
+    auto issue = [&](const int buf) {
+        const unsigned char *fa = (const unsigned char *)dY + ((size_t)ld_n * g.K * g.P + ld_p0) * 2;        // wave-uniform
+        const unsigned char *fb = (const unsigned char *)X + ((size_t)ld_n * g.C * g.P + ld_p0) * 2;
+        unsigned char *la = cl_smem + buf * BUF + wave * 1024, *lb = la + ABYTES;
+        const int left = g.P - ld_p0;             // pixels of the plane from this tile's first one on
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            // whole chunk inside the plane: as it lies; the 4-pixel end chunk: 4 pixels (8 bytes) early; beyond the plane: zeros
+            const int room = left - scx[u];
+            const unsigned char *sa = room >= 8 ? fa + aoff[u] : room > 0 ? fa + aoff[u] - 8 : (const unsigned char *)g.zero;
+            const unsigned char *sb = room >= 8 ? fb + boff[u] : room > 0 ? fb + boff[u] - 8 : (const unsigned char *)g.zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sa,
+                                             (__attribute__((address_space(3))) void *)(la + u * 4096), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sb,
+                                             (__attribute__((address_space(3))) void *)(lb + u * 4096), 16, 0, 0);
+        }
+        ld_r++;
+        ld_p0 += 64;
+        if (ld_p0 >= g.ptiles * 64) { ld_p0 = 0; ld_n++; }
+    };
+    const int fr = lane & 31, fk = lane >> 5;
+    // nsub: 16-pixel sub-steps that hold pixels; cut: chunk (of the tile's eight) that is the shifted 4-pixel end chunk, or -1
+    auto compute_n = [&](const int buf, const int nsub, const int cut, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const unsigned char *as = cl_smem + buf * BUF, *bs = as + ABYTES;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            if (!FULL && s >= nsub) break;
+            bf16x8 av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int row = wm * 64 + i * 32 + fr;
+                av[i] = *(const bf16x8 *)(as + row * 128 + (((2 * s + fk) ^ cl_key(row)) * 16));
+                if (!FULL && 2 * s + fk == cut) { u32x4 v = *(u32x4 *)&av[i]; v[0] = 0u; v[1] = 0u; av[i] = *(bf16x8 *)&v; }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int row = wn * 64 + j * 32 + fr;
+                bv[j] = *(const bf16x8 *)(bs + row * 128 + (((2 * s + fk) ^ cl_key(row)) * 16));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    if (r_beg < r_end) {
+        issue(0);
+        const int full = g.P >> 6, tail = g.P & 63, tail_sub = (tail + 15) >> 4, tail_cut = rem8 ? tail >> 3 : -1;
+        int it = r_beg, tin = tin0;
+        while (it < r_end) {
+            const int nf = min(r_end - it, full - tin);
+            for (int k = 0; k < nf; k++, it++) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (it + 1 < r_end) issue((it + 1 - r_beg) & 1);
+                compute_n((it - r_beg) & 1, 4, -1, std::true_type{});
+            }
+            tin += max(nf, 0);
+            if (it < r_end && tin == full && g.ptiles > full) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (it + 1 < r_end) issue((it + 1 - r_beg) & 1);
+                compute_n((it - r_beg) & 1, tail_sub, tail_cut, std::false_type{});
+                it++; tin++;
+            }
+            if (tin >= g.ptiles) tin = 0;
+        }
+    }
+    // partials [split][k][c]
+    float *o = part + ((size_t)split * g.K) * g.C + c0 + wn * 64 + (lane & 31);
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -857,8 +992,8 @@ int mid_cl_wgrad(mid_stream s, const void *xp, const void *dy, float *dw, float 
     g.rlen = mi_cdiv(g.rtiles, splits);
     const int used = mi_cdiv(g.rtiles, g.rlen);
     g.ctiles = C / 128; g.mtiles = K / 128;
-    g.fdGW = make_fastdiv(g.GW); g.fdPt = make_fastdiv(g.ptiles); g.fdM = make_fastdiv(g.mtiles); g.fdS = make_fastdiv(used); g.fd9 = make_fastdiv(9);
-    g.splits = (uint32_t)used; g.total8 = (uint32_t)(g.mtiles * g.ctiles * 9 * used) & ~7u;
+    g.fdGW = make_fastdiv(g.GW); g.fdPt = make_fastdiv(g.ptiles); g.fdM = make_fastdiv(g.mtiles); g.fdT = make_fastdiv(g.mtiles * g.ctiles * 9); g.fd9 = make_fastdiv(9);
+    g.tiles = (uint32_t)(g.mtiles * g.ctiles * 9); g.total8 = (uint32_t)(g.mtiles * g.ctiles * 9 * used) & ~7u;
     g.zero = (const u16 *)g_cl_zero;
     static int attr_set = 0;
     if (!attr_set) {
@@ -871,6 +1006,59 @@ int mid_cl_wgrad(mid_stream s, const void *xp, const void *dy, float *dw, float 
     mi_prof_end(st);
     if (rr) return rr;
     MI_LAUNCH_CHECK("cl_wgrad_kernel");
+    return 0;
+}
+static int pw_wgrad_splits(int N, int C, int K, int P) {
+    const long tiles = (long)(K / 128) * (C / 128), rt = (long)N * ((P + 63) / 64);
+    int best = 1;
+    double best_eff = 0;
+    for (int sp = 1; sp <= 512; sp++) {
+        if (sp > 1 && rt / sp < 16) break;
+        const double waves = (double)tiles * sp / 512.0;
+        const double eff = waves / (double)((long)((tiles * sp + 511) / 512));
+        if (eff > best_eff + 0.02) { best_eff = eff; best = sp; }
+    }
+    return best;
+}
+/* weight gradient of a 1x1 stride-1 convolution from the NCHW bf16 tensors: C % 128, K % 128, planes a multiple of 4 pixels */
+int mid_pw_wgrad_supported(int N, int C, int H, int K) {
+    const long P = (long)H * H;
+    if (C % 128 || K % 128 || P % 4 || P < 8) return 0;
+    if ((double)N * C * P >= 2147480000.0 || (double)N * K * P >= 2147480000.0) return 0;
+    if ((double)K * P * 2 >= 4294000000.0 || (double)C * P * 2 >= 4294000000.0) return 0;
+    return 1;
+}
+size_t mid_pw_wgrad_part_floats(int N, int C, int H, int K) { return (size_t)pw_wgrad_splits(N, C, K, H * H) * K * C; }
+int mid_pw_wgrad(mid_stream s, const void *x, const void *dy, float *dw, float *part, size_t part_floats, int N, int C, int H, int K) {
+    hipStream_t st = (hipStream_t)s;
+    if (!mid_pw_wgrad_supported(N, C, H, K)) { mi_record_error("mid_pw_wgrad", "shape not covered"); return -2; }
+    if (!g_cl_zero) {
+        if (hipMalloc(&g_cl_zero, 512) != hipSuccess) { mi_record_error("mid_pw_wgrad", "zero page"); return -1; }
+        (void)hipMemsetAsync(g_cl_zero, 0, 512, st);
+    }
+    PwWgArgs g = {};
+    g.K = K; g.C = C; g.P = H * H;
+    g.ptiles = (g.P + 63) / 64; g.rtiles = N * g.ptiles;
+    const int splits = pw_wgrad_splits(N, C, K, g.P);
+    if (part_floats < (size_t)splits * K * C) { mi_record_error("mid_pw_wgrad", "workspace too small"); return -3; }
+    g.rlen = mi_cdiv(g.rtiles, splits);
+    const int used = mi_cdiv(g.rtiles, g.rlen);
+    g.mtiles = K / 128;
+    const int tiles = g.mtiles * (C / 128);
+    g.fdPt = make_fastdiv(g.ptiles); g.fdM = make_fastdiv(g.mtiles); g.fdT = make_fastdiv(tiles);
+    g.tiles = (uint32_t)tiles; g.total8 = (uint32_t)(tiles * used) & ~7u;
+    g.zero = (const u16 *)g_cl_zero;
+    static int attr_set = 0;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)pw_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess) { mi_record_error("pw_wgrad_kernel", "cannot raise the dynamic LDS limit"); return -1; }
+        attr_set = 1;
+    }
+    mi_prof_begin(st, MI_FAM_WGRAD, 2.0 * (double)N * g.P * C * K, 2.0 * ((double)N * C * g.P + (double)N * g.P * K) + 4.0 * C * K);
+    hipLaunchKernelGGL(pw_wgrad_kernel, dim3(tiles * used), dim3(256), 65536, st, (const u16 *)dy, (const u16 *)x, part, g);
+    const int rr = mi_igemm_wgrad_reduce(st, part, dw, K, C, 1, used);
+    mi_prof_end(st);
+    if (rr) return rr;
+    MI_LAUNCH_CHECK("pw_wgrad_kernel");
     return 0;
 }
 /* y (bf16 NCHW) = conv3x3 (stride 1 or 2, pad 1) of the re-laid input xp with a_tiles = the forward k-step tiles [t][c/64][K][64]

@@ -147,6 +147,7 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
     // ---- block -> tile (XCD-contiguous, M-tiles fastest); blocks past g.full are reduction slices of the last tiles ----
     uint32_t L = blockIdx.x;
     int tail_id = -1, it0 = 0, nt_slice = 0;
+    uint32_t wg_split = blockIdx.y;
     if (MODE != IG_WGRAD && g.tsplit > 1 && L >= (uint32_t)g.full) {
         tail_id = (int)(L - (uint32_t)g.full);
         const uint32_t tl = fd_div((uint32_t)tail_id, g.fdTs);
@@ -154,6 +155,15 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
         L = (uint32_t)g.full + tl;
         it0 = z * g.tklen;
         nt_slice = g.tklen;
+    } else if (MODE == IG_WGRAD && gridDim.y >= 8) {
+        // wgrad with at least as many splits as XCDs: (tile, split) from a SPLIT-major list cut into eight contiguous pieces, one per XCD
+        // (workgroups go to the XCDs round-robin by linear id): all the tiles that reduce over one stretch of pixels run on one XCD at
+        // about the same time, so each operand byte is fetched from HBM by one L2
+        const uint32_t T_ = gridDim.x, tot = T_ * gridDim.y, per = tot >> 3;
+        uint32_t V = blockIdx.y * T_ + blockIdx.x;
+        if (V < per * 8) V = (V & 7) * per + (V >> 3);
+        wg_split = V / T_;
+        L = V - wg_split * T_;
     } else {
         const uint32_t lim = MODE != IG_WGRAD && g.tsplit > 1 ? (uint32_t)g.full : (uint32_t)g.tiles;
         const uint32_t per = lim >> 3;
@@ -236,7 +246,7 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
             cblk = (int)(ct - (uint32_t)wg_t * g.ctiles) * 128;
         }
         wg_r = wg_t / KS; wg_s = wg_t - KS * wg_r;
-        const int kbeg = (int)blockIdx.y * g.klen;
+        const int kbeg = (int)wg_split * g.klen;
         kend = min(g.N * g.P, kbeg + g.klen);
         ntiles = (kend - kbeg + IG_BK - 1) / IG_BK;
     }
@@ -251,7 +261,7 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
         ld_c0 = (it0 - ld_t * g.cpt) * IG_BK;
         ntiles = min(nt_slice, ntiles - it0);
     }
-    int ld_k0 = (MODE == IG_WGRAD) ? (int)blockIdx.y * g.klen : 0;
+    int ld_k0 = (MODE == IG_WGRAD) ? (int)wg_split * g.klen : 0;
     const char *fa = nullptr, *fb = nullptr; // wave-uniform bases of the tile being fetched (set by part 0)
     uint32_t fa_lane = 0, fb_lane = 0;       // per-lane byte offsets of the tile being fetched
     uint32_t fb_lane2 = 0;                   // CT64: the second tap's offset (sel_b bit 1 = its validity)
@@ -589,7 +599,7 @@ igemm_kernel(const float *__restrict__ Aop, const float *__restrict__ Bop, float
             const int lc = wn * WNC + j * 32 + (lane & 31);      // column of the tile
             const int tap = CT64 ? wg_t + (lc >> 6) : wg_t;
             cok = tap < T;
-            coff = ((size_t)((size_t)blockIdx.y * T + tap) * g.K) * g.C + (CT64 ? (lc & 63) : cblk + lc);
+            coff = ((size_t)((size_t)wg_split * T + tap) * g.K) * g.C + (CT64 ? (lc & 63) : cblk + lc);
             rstride = (size_t)g.C;
         } else {
             cok = col < g.ncols;

@@ -303,6 +303,8 @@ int mi_op_maxpool_bwd_t(const int *max_inds, const void *dy, void *dx, int dt, i
 int mi_op_avgpool_fwd_t(const void *x, int dt, float *y, int N, int C, int H) { return finish(mid_avgpool_fwd_t(mi_global()->compute, x, dt, y, N, C, H * H)); }
 int mi_op_avgpool_bwd_t(const float *dy, void *dx, int dt, int N, int C, int H) { return finish(mid_avgpool_bwd_t(mi_global()->compute, dy, dx, dt, N, C, H * H)); }
 int mi_bf16_conv_supported(int op, int N, int C, int H, int K, int k, int stride) { return mid_bf16_supported(op, N, C, H, K, k, stride); }
+/* 1: the 1x1 weight gradient of this shape runs on the LDS-DMA kernel (pw_wgrad_kernel) inside mi_op_conv_wgrad_bf16 / the bf16 trainer */
+int mi_bf16_pw_wgrad_supported(int N, int C, int H, int K) { return mid_pw_wgrad_supported(N, C, H, K); }
 void mi_clear_error(void) { mid_clear_error(); }
 
 /* the device-side merge of cross-replica batch norm on R replicas held by one process (see mid_bn_debug_merge): lets a one-GPU

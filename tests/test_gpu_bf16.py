@@ -617,6 +617,23 @@ def test_conv_dgrad_bf16_channel_last(ops, oracle, shape, with_addend):
     check_bf(nhwc(got), ref, "channel-last conv dgrad %s" % (shape,))
 
 
+PW_WG_SHAPES = [(128, 28, 512, 2), (512, 28, 128, 3), (256, 56, 128, 1), (1024, 14, 512, 5), (256, 14, 1024, 4), (128, 6, 128, 3), (128, 4, 256, 5),
+                (256, 10, 128, 3), (128, 12, 384, 2)]
+
+
+@pytest.mark.parametrize("shape", PW_WG_SHAPES, ids=["C%d_H%d_K%d_N%d" % s for s in PW_WG_SHAPES])
+def test_conv_wgrad_1x1_bf16_lds_dma(ops, oracle, shape):
+    """pw_wgrad_kernel: the 1x1 weight gradient with both NCHW operands staged as they lie by LDS-DMA.  Planes of 784 / 3136 pixels (whole
+    16-byte chunks), 196 / 36 / 100 (a 4-pixel end chunk: loaded 4 pixels early, its duplicated half zeroed in the dY fragment), 16 and 144
+    (tail tiles of 1 and 1 sub-steps); splits that begin in the middle of an image.  Same oracle and band as the NCHW kernel it replaces."""
+    C, H, K, N = shape
+    assert ops.L.mi_bf16_pw_wgrad_supported(N, C, H, K) == 1
+    x, w, dy = _conv_data(C, H, K, 1, 1, N)
+    ref = oracle.conv_wgrad(x, dy, 1, 1)
+    got = ops.conv_wgrad_bf16(nchw(x), nchw(dy), 1, 1)
+    check_grad(got, ref, "conv_wgrad_bf16 1x1 (LDS-DMA) %s" % (shape,))
+
+
 CL_D2_SHAPES = [(128, 56, 128, 2), (256, 56, 512, 1), (256, 28, 256, 3), (512, 28, 1024, 2), (512, 14, 512, 2), (1024, 14, 2048, 1), (128, 8, 128, 4), (128, 12, 64, 3), (256, 6, 128, 5)]
 
 
