@@ -183,7 +183,10 @@ cl_conv_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ In, u16 *__r
         for (int u = 0; u < NBU; u++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(fb + boff[u]),
                                              (__attribute__((address_space(3))) void *)(lb + u * 4096), 16, 0, 0);
-        if (++ld_c == cpt) { ld_c = 0; ld_t++; }
+        // taps fastest: the nine k-steps of one 64-channel chunk read the same 128-byte lines of neighbouring pixels back to back, so the
+        // re-reads hit in L2 (channel chunks fastest streamed BN x Cin x 2 bytes per workgroup between two uses of a line: 16 MB per XCD
+        // at 1024 channels, four times its L2, and every tap went back to memory)
+        if (++ld_t == g.ntaps) { ld_t = 0; ld_c++; }
     };
     const int fr = lane & 31, fk = lane >> 5;
     auto compute = [&](const int buf) {
@@ -428,7 +431,9 @@ cl_dgrad2_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ In, u16 *_
         for (int u = 0; u < 4; u++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(fb + boff[u]),
                                              (__attribute__((address_space(3))) void *)(lb + u * 4096), 16, 0, 0);
-        if (++ld_c == cpt) { ld_c = 0; ld_i++; }
+        // taps fastest within a column parity (see cl_conv_kernel)
+        if (ld_i < nrt) { if (++ld_i == nrt) { ld_i = 0; if (++ld_c == cpt) { ld_c = 0; ld_i = nrt; } } }
+        else if (++ld_i == 3 * nrt) { ld_i = nrt; ld_c++; }
     };
     const int fr = lane & 31, fk = lane >> 5;
     auto compute = [&](const int buf, auto w_tag) {
