@@ -947,6 +947,14 @@ int mid_cl_dgrad2(mid_stream s, const void *dyp, const void *a_tiles, void *dx, 
     return 0;
 }
 static void *g_cl_zero = nullptr;
+/* 512 zero bytes that pieces beyond a plane are loaded from; made once, and complete before the first launch on ANY stream */
+static int cl_zero_page(const char *who) {
+    if (g_cl_zero) return 0;
+    void *p = nullptr;
+    if (hipMalloc(&p, 512) != hipSuccess || hipMemset(p, 0, 512) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { mi_record_error(who, "zero page"); return -1; }
+    g_cl_zero = p;
+    return 0;
+}
 static int cl_wgrad_splits(int N, int C, int K, int P) {
     const long tiles = (long)(K / 128) * (C / 128) * 9, rt = (long)N * ((P + CLW_KPX - 1) / CLW_KPX);
     int best = 1;
@@ -974,10 +982,7 @@ size_t mid_cl_wgrad_part_floats(int N, int C, int H, int K, int stride) {
 int mid_cl_wgrad(mid_stream s, const void *xp, const void *dy, float *dw, float *part, size_t part_floats, int N, int C, int H, int K, int stride) {
     hipStream_t st = (hipStream_t)s;
     if (!mid_cl_wgrad_supported(N, C, H, K, stride)) { mi_record_error("mid_cl_wgrad", "shape not covered"); return -2; }
-    if (!g_cl_zero) {
-        if (hipMalloc(&g_cl_zero, 512) != hipSuccess) { mi_record_error("mid_cl_wgrad", "zero page"); return -1; }
-        (void)hipMemsetAsync(g_cl_zero, 0, 512, st);
-    }
+    if (cl_zero_page("mid_cl_wgrad")) return -1;
     ClWgArgs g = {};
     g.K = K; g.C = C; g.GW = H / stride; g.P = g.GW * g.GW;
     if (stride == 2) {
@@ -1037,10 +1042,7 @@ size_t mid_pw_wgrad_part_floats(int N, int C, int H, int K) { return (size_t)pw_
 int mid_pw_wgrad(mid_stream s, const void *x, const void *dy, float *dw, float *part, size_t part_floats, int N, int C, int H, int K) {
     hipStream_t st = (hipStream_t)s;
     if (!mid_pw_wgrad_supported(N, C, H, K)) { mi_record_error("mid_pw_wgrad", "shape not covered"); return -2; }
-    if (!g_cl_zero) {
-        if (hipMalloc(&g_cl_zero, 512) != hipSuccess) { mi_record_error("mid_pw_wgrad", "zero page"); return -1; }
-        (void)hipMemsetAsync(g_cl_zero, 0, 512, st);
-    }
+    if (cl_zero_page("mid_pw_wgrad")) return -1;
     PwWgArgs g = {};
     g.K = K; g.C = C; g.P = H * H;
     g.ptiles = (g.P + 63) / 64; g.rtiles = N * g.ptiles;
@@ -1058,7 +1060,7 @@ int mid_pw_wgrad(mid_stream s, const void *x, const void *dy, float *dw, float *
         if (hipFuncSetAttribute((const void *)pw_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess) { mi_record_error("pw_wgrad_kernel", "cannot raise the dynamic LDS limit"); return -1; }
         attr_set = 1;
     }
-    mi_prof_begin(st, MI_FAM_WGRAD, 2.0 * (double)N * g.P * C * K, 2.0 * ((double)N * C * g.P + (double)N * g.P * K) + 4.0 * C * K);
+    mi_prof_begin(st, MI_FAM_GEMM, 2.0 * (double)N * g.P * C * K, 2.0 * ((double)N * C * g.P + (double)N * g.P * K) + 4.0 * C * K);
     hipLaunchKernelGGL(pw_wgrad_kernel, dim3(tiles * used), dim3(256), 65536, st, (const u16 *)dy, (const u16 *)x, part, g);
     const int rr = mi_igemm_wgrad_reduce(st, part, dw, K, C, 1, used);
     mi_prof_end(st);

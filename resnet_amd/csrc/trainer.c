@@ -365,22 +365,24 @@ static void size_workspaces(MiCtx *c, const Dims *d, ConvBlock **blocks, int N) 
             const ConvBlock *b = blocks[i];
             if (b->stride != 2) continue;
             const size_t H = b->incoming_spatial_dim, e1 = (size_t)N * b->reduced_depth * H * H, e2 = (size_t)N * b->incoming_filters * H * H;
-            c->par[i].spatial_bytes = e1 * 2;
-            c->par[i].spatial = (char *)mi_ctx_alloc(c, e1 * 2 + 2 * MI_GUARD) + MI_GUARD;
-            if (b->projection) { c->par[i].proj_bytes = e2 * 2; c->par[i].proj = (char *)mi_ctx_alloc(c, e2 * 2 + 2 * MI_GUARD) + MI_GUARD; }
             /* forward and weight gradient on channel-last parity planes (RESNET_MI_BF16_CL_S2=0: the NCHW kernels and their planes) */
+            int need_sp = 1, need_pr = b->projection != NULL;
             if (!(getenv("RESNET_MI_BF16_CL_S2") && atoi(getenv("RESNET_MI_BF16_CL_S2")) == 0)) {
                 if (mid_cl_supported(0, N, b->reduced_depth, (int)H, b->reduced_depth, 2)) {
                     const size_t by = mid_cl_operand_bytes(0, N, b->reduced_depth, (int)H, b->reduced_depth, 2);
                     c->par[i].cl_spatial = mi_ctx_alloc(c, by);
                     mid_memset(c->par[i].cl_spatial, 0, by, G.compute); /* the halo stays zero: the re-layout writes the interior only */
+                    need_sp = !mid_cl_wgrad_supported(N, b->reduced_depth, (int)H, b->reduced_depth, 2); /* (7x7 outputs: the NCHW wgrad and its planes) */
                 }
                 if (b->projection && mid_cl_supported(0, N, b->incoming_filters, (int)H, b->expanded_depth, 2)) {
                     const size_t by = mid_cl_operand_bytes(0, N, b->incoming_filters, (int)H, b->expanded_depth, 2);
                     c->par[i].cl_proj = mi_ctx_alloc(c, by);
                     mid_memset(c->par[i].cl_proj, 0, by, G.compute);
+                    need_pr = !mid_cl_wgrad_supported(N, b->incoming_filters, (int)H, b->expanded_depth, 2);
                 }
             }
+            if (need_sp) { c->par[i].spatial_bytes = e1 * 2; c->par[i].spatial = (char *)mi_ctx_alloc(c, e1 * 2 + 2 * MI_GUARD) + MI_GUARD; }
+            if (need_pr) { c->par[i].proj_bytes = e2 * 2; c->par[i].proj = (char *)mi_ctx_alloc(c, e2 * 2 + 2 * MI_GUARD) + MI_GUARD; }
             /* the stride-2 dgrads on channel-last dY (RESNET_MI_BF16_CL_DGRAD2=0: the NCHW kernel's four parity classes) */
             if (!(getenv("RESNET_MI_BF16_CL_DGRAD2") && atoi(getenv("RESNET_MI_BF16_CL_DGRAD2")) == 0)) {
                 if (mid_cl_dgrad2_supported(N, b->reduced_depth, (int)H, b->reduced_depth)) {
