@@ -142,7 +142,7 @@ def test_bn_add_relu_and_external_mask(ops, oracle, C, H, N):
     assert np.array_equal(hdx, gdx) and np.array_equal(hdg, gdg) and np.array_equal(hdb, gdb)
 
 
-@pytest.mark.parametrize("C,H,N", [(64, 112, 2), (64, 16, 4)])
+@pytest.mark.parametrize("C,H,N", [(64, 112, 2), (64, 16, 4), (64, 12, 3)])  # 12: rows that are not whole 8-element vectors -> the generic kernel
 def test_maxpool(ops, oracle, C, H, N):
     x = np.maximum(rand((N, H, H, C), 21), 0)  # post-ReLU input: ties at 0 exercise "first max wins"
     y, idx = oracle.maxpool_fwd(x, 3, 2)
