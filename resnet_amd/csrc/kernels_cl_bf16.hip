@@ -903,19 +903,24 @@ size_t mid_cl_operand_bytes(int op, int N, int C, int H, int K, int stride) {
 /* x (bf16 NCHW, C channels, H x H) -> the padded channel-last operand; the halo of xp must be zero (zero the buffer once when it is made).
  * parity != 0: the four parity planes of a stride-2 forward; else one plane with a halo of 1 */
 int mid_cl_relayout(mid_stream s, const void *x, void *xp, int N, int C, int H, int parity) {
+    /* counted in the 3x3 family's time (no flops of its own): it is part of what the channel-last route costs */
+    mi_prof_begin((hipStream_t)s, MI_FAM_PCONV, 0.0, 4.0 * (double)N * C * H * H);
     if (parity) {
         const int Ho = H / 2;
         hipLaunchKernelGGL(cl_relayout_kernel<1>, dim3(C / 64, Ho, N), dim3(256), (size_t)2 * H * 72 * 2, (hipStream_t)s, (const u16 *)x, (u16 *)xp, C, H, H, Ho + 1, Ho + 1, 0, 0);
     } else {
         hipLaunchKernelGGL(cl_relayout64_kernel, dim3(C / 64, mi_cdiv(H * H, 64), N), dim3(256), 0, (hipStream_t)s, (const u16 *)x, (u16 *)xp, C, H * H, H, H + 2, H + 2, 1, 1, make_fastdiv(H));
     }
+    mi_prof_end((hipStream_t)s);
     MI_LAUNCH_CHECK("cl_relayout_kernel");
     return 0;
 }
 /* dY (bf16 NCHW, K channels, Ho x Ho) -> channel-last with one zero row / column at the far end: the operand of the stride-2 dgrad */
 int mid_cl_relayout_end(mid_stream s, const void *dy, void *dyp, int N, int K, int Ho) {
+    mi_prof_begin((hipStream_t)s, MI_FAM_PCONV, 0.0, 4.0 * (double)N * K * Ho * Ho);
     hipLaunchKernelGGL(cl_relayout64_kernel, dim3(K / 64, mi_cdiv(Ho * Ho, 64), N), dim3(256), 0, (hipStream_t)s, (const u16 *)dy, (u16 *)dyp, K, Ho * Ho, Ho, Ho + 1, Ho + 1, 0, 0,
                        make_fastdiv(Ho));
+    mi_prof_end((hipStream_t)s);
     MI_LAUNCH_CHECK("cl_relayout64_kernel");
     return 0;
 }

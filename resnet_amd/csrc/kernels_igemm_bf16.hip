@@ -1023,7 +1023,9 @@ static int bg_s2d(hipStream_t st, const u16 *x, u16 *out, long NC, int H, int W)
     if (units >= 2147483648L) { mi_record_error("bg_s2d", "tensor too large"); return -2; }
     long blocks = (units + 255) / 256;
     if (blocks > 65536 * 8) blocks = 65536 * 8;
+    mi_prof_begin(st, MI_FAM_PCONV, 0.0, 4.0 * (double)NC * H * W); /* part of the stride-2 layers' cost: counted in the 3x3 family's time */
     hipLaunchKernelGGL(bg_s2d_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, out, (uint32_t)units, H, W, make_fastdiv(UW), make_fastdiv(Ho));
+    mi_prof_end(st);
     MI_LAUNCH_CHECK("bg_s2d_kernel");
     return 0;
 }
