@@ -710,6 +710,133 @@ cl_wgrad_kernel(const u16 *__restrict__ dY, const u16 *__restrict__ Xc, float *_
                 o[(size_t)(m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * g.C + j * 32] = acc[i][j][r];
 }
 
+// Weight gradient with BOTH operands channel-last (stride 2): A = the dY planes the stride-2 dgrad already uses ([N][Ho+1][Wo+1][K], zero row /
+// column at the far end), B = the input's parity planes.  The reduction runs over the N * Ho * Wo pixels as ONE flat list in tiles of 64 --
+// a tile may straddle images, so planes of 49 or 196 pixels waste nothing -- and every 16-byte DMA piece is addressed through its own
+// pixel's (image, row, column), kept incrementally per thread (the four pixel rows a thread stages are the same for A and for B).  Both
+// fragments are transposed reads (ds_read_b64_tr_b16) of [64 pixels][128 channels] LDS images.  Tiles, splits, XCD placement, two-stage
+// fixed-order sum as cl_wgrad_kernel.
+struct ClWg2Args {
+    int K, C;
+    int GH, GW;                     // output plane
+    int R;                          // reduction length = N * GH * GW pixels
+    int rtiles, rlen;               // 64-pixel tiles in all; per split
+    int img_rows, Wp;               // parity-plane geometry of the input (as ClArgs)
+    uint32_t a_rowb, a_imgb;        // bytes of one dY plane row / one dY image ((Wo+1) K 2, (Ho+1)(Wo+1) K 2)
+    int ctiles, mtiles;
+    uint32_t tap_delta[9];
+    FastDiv fdGW, fdP, fdM, fdT, fd9;
+    uint32_t tiles, total8;
+    const u16 *zero;
+};
+__global__ void __launch_bounds__(256, 2)
+cl_wgrad2_kernel(const u16 *__restrict__ dYc, const u16 *__restrict__ Xc, float *__restrict__ part, const ClWg2Args g) {
+    constexpr int ABYTES = 64 * 256, BUF = 2 * ABYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char cl_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    uint32_t L = blockIdx.x;
+    if (L < g.total8) L = (L & 7u) * (g.total8 >> 3) + (L >> 3);
+    const uint32_t split = fd_div(L, g.fdT), tile = L - split * g.tiles;
+    const uint32_t tc = fd_div(tile, g.fd9), t = tile - tc * 9u;
+    const uint32_t ct = fd_div(tc, g.fdM);
+    const int m0 = (int)(tc - ct * g.mtiles) * 128, c0 = (int)ct * 128;
+    const int r_beg = (int)split * g.rlen, r_end = min(g.rtiles, r_beg + g.rlen);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    // piece p = tid + 256 u of either image: pixel row p >> 4, LDS chunk p & 15, which holds source chunk (p & 15) ^ key(row) (8 channels)
+    const int brow = tid >> 4, bchunk = tid & 15;
+    const uint32_t rowb = (uint32_t)g.Wp * g.C * 2u, colb = (uint32_t)g.C * 2u, imgb = (uint32_t)g.img_rows * rowb;
+    const uint32_t acolb = (uint32_t)g.K * 2u;
+    const uint32_t q64 = fd_div(64u, g.fdGW), r64 = 64u - q64 * g.GW;
+    const uint32_t tdelta = g.tap_delta[t] + (uint32_t)c0 * 2u;
+    uint32_t rn[4], ry[4], rx[4], lanec[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int row = brow + 16 * u;
+        const uint32_t j = (uint32_t)r_beg * 64u + (uint32_t)row;      // may lie past the end: such rows load the zero page
+        const uint32_t n = fd_div(j, g.fdP), pp = j - n * (uint32_t)(g.GH * g.GW);
+        const uint32_t y = fd_div(pp, g.fdGW);
+        rn[u] = n; ry[u] = y; rx[u] = pp - y * g.GW;
+        lanec[u] = (uint32_t)((bchunk ^ cl_keyb(row)) * 16);
+    }
+    int ld_j0 = r_beg * 64;
+    auto issue = [&](const int buf) {
+        unsigned char *la = cl_smem + buf * BUF + wave * 1024, *lb = la + ABYTES;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool ok = ld_j0 + brow + 16 * u < g.R;
+            const unsigned char *sa = (const unsigned char *)dYc + (rn[u] * g.a_imgb + ry[u] * g.a_rowb + rx[u] * acolb + (uint32_t)m0 * 2u + lanec[u]);
+            const unsigned char *sb = (const unsigned char *)Xc + (rn[u] * imgb + ry[u] * rowb + rx[u] * colb + tdelta + lanec[u]);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ok ? sa : (const unsigned char *)g.zero),
+                                             (__attribute__((address_space(3))) void *)(la + u * 4096), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ok ? sb : (const unsigned char *)g.zero),
+                                             (__attribute__((address_space(3))) void *)(lb + u * 4096), 16, 0, 0);
+        }
+        ld_j0 += 64;
+#pragma unroll
+        for (int u = 0; u < 4; u++) { // 64 pixels on: q64 rows and r64 columns further, carried into the row and the image
+            uint32_t nx = rx[u] + r64;
+            const uint32_t carry = nx >= (uint32_t)g.GW ? 1u : 0u;
+            rx[u] = nx - carry * (uint32_t)g.GW;
+            uint32_t ny = ry[u] + q64 + carry;
+            while (ny >= (uint32_t)g.GH) { ny -= (uint32_t)g.GH; rn[u]++; }
+            ry[u] = ny;
+        }
+    };
+    const int fk = lane >> 5;
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tcb = (lane >> 4) & 1;
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    auto frag = [&](const unsigned char *img, const int s, const int chan0) -> bf16x8 { // 8 consecutive pixels of one channel per lane
+        const int ch0 = chan0 / 8 + 2 * tcb + (tp >> 1);
+        const int row0 = 16 * s + 8 * fk + tq, row1 = row0 + 4;
+        const cl_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) cl_s16x4 *)(img + row0 * 256 + ((ch0 ^ cl_keyb(row0)) * 16) + 8 * (tp & 1)));
+        const cl_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) cl_s16x4 *)(img + row1 * 256 + ((ch0 ^ cl_keyb(row1)) * 16) + 8 * (tp & 1)));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return *(bf16x8 *)&v;
+    };
+    auto compute = [&](const int buf) {
+        const unsigned char *as = cl_smem + buf * BUF, *bs = as + ABYTES;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            bf16x8 av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) av[i] = frag(as, s, wm * 64 + i * 32);
+#pragma unroll
+            for (int j = 0; j < 2; j++) bv[j] = frag(bs, s, wn * 64 + j * 32);
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    if (r_beg < r_end) {
+        issue(0);
+        for (int it = r_beg; it < r_end; it++) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (it + 1 < r_end) issue((it + 1 - r_beg) & 1);
+            compute((it - r_beg) & 1);
+        }
+    }
+    float *o = part + ((size_t)((size_t)split * 9 + t) * g.K) * g.C + c0 + wn * 64 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                o[(size_t)(m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * g.C + j * 32] = acc[i][j][r];
+}
+
 // Weight gradient of a 1x1 convolution, both operands as they lie (bf16 NCHW):  dW[k][c] = sum over images and pixels dY[n][k][p] * X[n][c][p].
 // The reduction index (pixels) is the contiguous one of BOTH operands, so both stage by LDS-DMA into [128 channels][64 pixels] images of
 // 128-byte rows (XOR-swizzled 16-byte chunks) and both fragments are plain ds_read_b128.  Tiles, splits, XCD placement and the two-stage
@@ -1021,6 +1148,62 @@ int mid_cl_wgrad(mid_stream s, const void *xp, const void *dy, float *dw, float 
     mi_prof_end(st);
     if (rr) return rr;
     MI_LAUNCH_CHECK("cl_wgrad_kernel");
+    return 0;
+}
+static int cl_wgrad2_splits(int N, int C, int K, int P) {
+    const long tiles = (long)(K / 128) * (C / 128) * 9, rt = ((long)N * P + 63) / 64;
+    int best = 1;
+    double best_eff = 0;
+    for (int sp = 1; sp <= 256; sp++) {
+        if (sp > 1 && rt / sp < 24) break;
+        const double waves = (double)tiles * sp / 512.0;
+        const double eff = waves / (double)((long)((tiles * sp + 511) / 512));
+        if (eff > best_eff + 0.02) { best_eff = eff; best = sp; }
+    }
+    return best;
+}
+/* weight gradient of a 3x3 stride-2 layer from the channel-last planes of BOTH operands: xp = mid_cl_relayout(parity) of the input,
+ * dyp = mid_cl_relayout_end of dY (what mid_cl_dgrad2 reads); C % 128, K % 128, any plane size */
+int mid_cl_wgrad2_supported(int N, int C, int H, int K) {
+    if (!mid_cl_supported(0, N, C, H, K, 2)) return 0;
+    if (C % 128 || K % 128) return 0;
+    if ((double)N * (H / 2 + 1) * (H / 2 + 1) * K * 2 >= 4294000000.0 || (double)N * (H / 2) * (H / 2) + 64 >= 2147480000.0) return 0;
+    return 1;
+}
+size_t mid_cl_wgrad2_part_floats(int N, int C, int H, int K) { return (size_t)cl_wgrad2_splits(N, C, K, (H / 2) * (H / 2)) * 9 * K * C; }
+int mid_cl_wgrad2(mid_stream s, const void *xp, const void *dyp, float *dw, float *part, size_t part_floats, int N, int C, int H, int K) {
+    hipStream_t st = (hipStream_t)s;
+    if (!mid_cl_wgrad2_supported(N, C, H, K)) { mi_record_error("mid_cl_wgrad2", "shape not covered"); return -2; }
+    if (cl_zero_page("mid_cl_wgrad2")) return -1;
+    ClWg2Args g = {};
+    g.K = K; g.C = C; g.GH = H / 2; g.GW = H / 2; g.R = N * g.GH * g.GW;
+    const int Hp = g.GW + 1;
+    g.img_rows = 4 * Hp; g.Wp = Hp;
+    for (int t = 0; t < 9; t++) {
+        const int r = t / 3, sx = t % 3, q = 2 * ((r + 1) & 1) + ((sx + 1) & 1);
+        g.tap_delta[t] = (uint32_t)(((q * Hp + (r > 0)) * Hp + (sx > 0)) * C) * 2u;
+    }
+    g.a_rowb = (uint32_t)Hp * K * 2u; g.a_imgb = (uint32_t)Hp * g.a_rowb;
+    g.rtiles = mi_cdiv(g.R, 64);
+    const int splits = cl_wgrad2_splits(N, C, K, g.GH * g.GW);
+    if (part_floats < (size_t)splits * 9 * K * C) { mi_record_error("mid_cl_wgrad2", "workspace too small"); return -3; }
+    g.rlen = mi_cdiv(g.rtiles, splits);
+    const int used = mi_cdiv(g.rtiles, g.rlen);
+    g.ctiles = C / 128; g.mtiles = K / 128;
+    g.fdGW = make_fastdiv(g.GW); g.fdP = make_fastdiv(g.GH * g.GW); g.fdM = make_fastdiv(g.mtiles); g.fdT = make_fastdiv(g.mtiles * g.ctiles * 9); g.fd9 = make_fastdiv(9);
+    g.tiles = (uint32_t)(g.mtiles * g.ctiles * 9); g.total8 = (uint32_t)(g.mtiles * g.ctiles * 9 * used) & ~7u;
+    g.zero = (const u16 *)g_cl_zero;
+    static int attr_set = 0;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)cl_wgrad2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess) { mi_record_error("cl_wgrad2_kernel", "cannot raise the dynamic LDS limit"); return -1; }
+        attr_set = 1;
+    }
+    mi_prof_begin(st, MI_FAM_PCONV, 2.0 * 9 * (double)g.R * C * K, 2.0 * ((double)N * C * H * H + (double)g.R * K) + 4.0 * 9 * C * K);
+    hipLaunchKernelGGL(cl_wgrad2_kernel, dim3(g.mtiles * g.ctiles * 9 * used), dim3(256), 65536, st, (const u16 *)dyp, (const u16 *)xp, part, g);
+    const int rr = mi_igemm_wgrad_reduce(st, part, dw, K, C, 3, used);
+    mi_prof_end(st);
+    if (rr) return rr;
+    MI_LAUNCH_CHECK("cl_wgrad2_kernel");
     return 0;
 }
 static int pw_wgrad_splits(int N, int C, int K, int P) {

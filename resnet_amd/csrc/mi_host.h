@@ -78,6 +78,7 @@ typedef struct MiCtx {
     /* bf16: the reduction pass of a unit's BN' done by the dgrad that produces its dy (mid_conv_dgrad_bn_bf16).  backwards_pass
      * fills fz_req before the unit whose dgrad should do it; the unit's dgrad moves it to fz_done (nparts > 0) for the next unit_bwd */
     mid_bn_bwd_parts fz_req, fz_done;
+    int cl_wgrad2;               /* bf16: stride-2 weight gradients with both operands channel-last where the plane does not fill 64-pixel tiles (RESNET_MI_BF16_CL_WGRAD2=0: off) */
     int fz_req_valid, fz_ready, fz_enable, fz_f32; /* fz_f32: the fp32 dgrads do it too (RESNET_MI_F32_BNFUSE_BWD, default on) */
     float *stem_dx;              /* bf16 mode: the stem convolution's output gradient stays fp32 */
     void *stem_xp; size_t stem_xp_bytes;           /* bf16 mode: the batch as zero-padded bf16 parity planes (kernels_stem_bf16.hip) */
@@ -89,6 +90,7 @@ typedef struct MiCtx {
     unsigned long host_epoch_seen; /* the process-wide host-write count (mi_copy_to_device) that re-layout was made at */
     void *cur_par; size_t cur_par_bytes; int *cur_par_valid; /* parity buffer of the stride-2 convolution about to be launched */
     void *cur_cl;                /* ... its channel-last parity planes (the forward pass fills them, the weight gradient reads them), or NULL */
+    int cur_dye_valid;           /* the stride-2 dgrad of this layer has filled cur_dye (this backward pass): the weight gradient may read it */
     void *cur_dye;               /* ... and the channel-last buffer for its output gradient (stride-2 dgrad), or NULL */
     char *dump_root;
     /* every device allocation of this trainer (freed by destroy_trainer) */

@@ -341,6 +341,7 @@ static void size_workspaces(MiCtx *c, const Dims *d, ConvBlock **blocks, int N) 
         size_t a_ = mid_conv_ws_wt_floats(C_, K_, k_), b_ = mid_conv_ws_part_floats(N, C_, H_, K_, k_, s_); \
         if (c->dtype == MID_BF16 && (k_) <= 3) { size_t e_ = mid_bf16_part_floats(N, C_, H_, K_, k_, s_); if (e_ > b_) b_ = e_; } \
         if (c->dtype == MID_BF16 && (k_) == 3 && mid_cl_wgrad_supported(N, C_, H_, K_, s_)) { size_t e_ = mid_cl_wgrad_part_floats(N, C_, H_, K_, s_); if (e_ > b_) b_ = e_; } \
+        if (c->dtype == MID_BF16 && (k_) == 3 && (s_) == 2 && mid_cl_wgrad2_supported(N, C_, H_, K_)) { size_t e_ = mid_cl_wgrad2_part_floats(N, C_, H_, K_); if (e_ > b_) b_ = e_; } \
         if (a_ > wt) wt = a_;                                                                 \
         if (b_ > part) part = b_;                                                             \
         if ((K_) > maxc) maxc = (K_);                                                         \
@@ -372,13 +373,13 @@ static void size_workspaces(MiCtx *c, const Dims *d, ConvBlock **blocks, int N) 
                     const size_t by = mid_cl_operand_bytes(0, N, b->reduced_depth, (int)H, b->reduced_depth, 2);
                     c->par[i].cl_spatial = mi_ctx_alloc(c, by);
                     mid_memset(c->par[i].cl_spatial, 0, by, G.compute); /* the halo stays zero: the re-layout writes the interior only */
-                    need_sp = !mid_cl_wgrad_supported(N, b->reduced_depth, (int)H, b->reduced_depth, 2); /* (7x7 outputs: the NCHW wgrad and its planes) */
+                    need_sp = !mid_cl_wgrad_supported(N, b->reduced_depth, (int)H, b->reduced_depth, 2) && !mid_cl_wgrad2_supported(N, b->reduced_depth, (int)H, b->reduced_depth);
                 }
                 if (b->projection && mid_cl_supported(0, N, b->incoming_filters, (int)H, b->expanded_depth, 2)) {
                     const size_t by = mid_cl_operand_bytes(0, N, b->incoming_filters, (int)H, b->expanded_depth, 2);
                     c->par[i].cl_proj = mi_ctx_alloc(c, by);
                     mid_memset(c->par[i].cl_proj, 0, by, G.compute);
-                    need_pr = !mid_cl_wgrad_supported(N, b->incoming_filters, (int)H, b->expanded_depth, 2);
+                    need_pr = !mid_cl_wgrad_supported(N, b->incoming_filters, (int)H, b->expanded_depth, 2) && !mid_cl_wgrad2_supported(N, b->incoming_filters, (int)H, b->expanded_depth);
                 }
             }
             if (need_sp) { c->par[i].spatial_bytes = e1 * 2; c->par[i].spatial = (char *)mi_ctx_alloc(c, e1 * 2 + 2 * MI_GUARD) + MI_GUARD; }
@@ -544,6 +545,7 @@ Train_ResNet *init_trainer(ResNet *model, Batch *cur_batch, int batch_size, floa
      * keeps lane = column, so the fused form reads x / mask / addend with 4-byte accesses (four times the memory instructions of the
      * bf16 kernel's row-major drain) and pays for it wherever the separate reduction pass was only 2 tensors; site 4 replaces a
      * 4-tensor pass and breaks even, so it is the default */
+    c->cl_wgrad2 = !(getenv("RESNET_MI_BF16_CL_WGRAD2") && atoi(getenv("RESNET_MI_BF16_CL_WGRAD2")) == 0);
     c->fz_f32 = mid_igemm_mode() >= 2 ? (getenv("RESNET_MI_F32_BNFUSE_BWD") ? atoi(getenv("RESNET_MI_F32_BNFUSE_BWD")) : 4) : 0;
     c->overlap_wgrad = getenv("RESNET_MI_OVERLAP") ? atoi(getenv("RESNET_MI_OVERLAP")) : 1;
     c->ev_bn_done = mid_event_create(); c->ev_wgrad_done = mid_event_create();
@@ -775,7 +777,7 @@ void mi_trainer_poll_errors(Train_ResNet *t) {
  * stem: the 7x7 convolution keeps fp32 input / output in every storage type; only its BN output is an activation tensor */
 /* c->cur_par: parity copy of the NEXT stride-2 convolution's input (set by the caller); c->cur_par_valid: where the forward pass
  * records whether it really wrote the planes (it does only on the 16-byte staging route), read back by the weight gradient */
-static void set_cur_par(MiCtx *c, void *buf, size_t bytes, int *valid) { c->cur_par = buf; c->cur_par_bytes = bytes; c->cur_par_valid = valid; c->cur_dye = NULL; c->cur_cl = NULL; }
+static void set_cur_par(MiCtx *c, void *buf, size_t bytes, int *valid) { c->cur_par = buf; c->cur_par_bytes = bytes; c->cur_par_valid = valid; c->cur_dye = NULL; c->cur_cl = NULL; c->cur_dye_valid = 0; }
 static void unit_fwd(Train_ResNet *t, const float *in, const float *w, const BatchNorm *bn, Cache_BatchNorm *cache,
                      float *conv_out, float *act_out, const float *residual, int C, int H, int K, int k, int stride,
                      int relu, int stem) {
@@ -914,6 +916,7 @@ static void conv_dgrad_t(Train_ResNet *t, const float *w, const float *dy, float
         /* stride-2 dgrad on channel-last dY: re-lay dY (K channels, H/2 x H/2) into the layer's zero-bordered buffer, then both column
          * parities of dx per workgroup by LDS-DMA staged MFMAs (dense stores; 1.5-1.9x the NCHW kernel's four parity classes) */
         ck(mid_cl_relayout_end(G.compute, dy, c->cur_dye, t->batch_size, K, H / 2), "dY re-layout (channel-last)");
+        c->cur_dye_valid = 1;
         ck(mid_cl_dgrad2(G.compute, c->cur_dye, we->dgrad, dx, t->batch_size, C, H, K), "convolution dgrad (bf16, channel-last, stride 2)");
         c->fz_req_valid = 0;
         c->ws.pre_dgrad = NULL;
@@ -940,6 +943,11 @@ static void conv_wgrad_t(Train_ResNet *t, mid_stream st, const float *x, const f
         ck(mid_stem_wgrad_f32(st, c->stem_xp, dy, dw, c->stem_scratch, c->stem_scratch_floats, t->batch_size, H), "stem convolution wgrad (fp32 matrix cores)");
     else if (stem && c->stem_scratch) /* the forward pass left the batch as padded bf16 parity planes */
         ck(mid_stem_wgrad_bf16(st, c->stem_xp, dy, dw, c->stem_scratch, c->stem_scratch_floats, t->batch_size, H), "stem convolution wgrad (bf16 operands)");
+    else if (c->dtype == MID_BF16 && !stem && k == 3 && stride == 2 && c->cur_cl && c->cur_dye && c->cur_dye_valid && c->cl_wgrad2 &&
+             mid_cl_wgrad2_supported(t->batch_size, C, H, K) && (((H / 2) * (H / 2)) % 64 != 0 || !mid_cl_wgrad_supported(t->batch_size, C, H, K, 2)))
+        /* both operands channel-last (the dY planes the dgrad has just made): planes that do not fill 64-pixel tiles (784, 196, 49 pixels:
+         * all of the benchmark network's stride-2 layers; -0.8 ms per step, most of it the two 7x7 layers the other kernel cannot take) */
+        ck(mid_cl_wgrad2(st, c->cur_cl, c->cur_dye, dw, c->ws.part, c->ws.part_floats, t->batch_size, C, H, K), "convolution wgrad (bf16, both operands channel-last)");
     else if (c->dtype == MID_BF16 && !stem && k == 3 && stride == 2 && c->cur_cl && mid_cl_wgrad_supported(t->batch_size, C, H, K, 2))
         ck(mid_cl_wgrad(st, c->cur_cl, dy, dw, c->ws.part, c->ws.part_floats, t->batch_size, C, H, K, 2), "convolution wgrad (bf16, channel-last)");
     else if (c->dtype == MID_BF16 && !stem) ck(mid_conv_wgrad_bf16(st, &c->ws, x, dy, dw, t->batch_size, C, H, K, k, stride), "convolution wgrad (bf16)");
