@@ -915,7 +915,7 @@ static void conv_dgrad_t(Train_ResNet *t, const float *w, const float *dy, float
     if (c->dtype == MID_BF16 && stride == 2 && k == 3 && !addend && c->cur_dye && we && we->dgrad) {
         /* stride-2 dgrad on channel-last dY: re-lay dY (K channels, H/2 x H/2) into the layer's zero-bordered buffer, then both column
          * parities of dx per workgroup by LDS-DMA staged MFMAs (dense stores; 1.5-1.9x the NCHW kernel's four parity classes) */
-        ck(mid_cl_relayout_end(G.compute, dy, c->cur_dye, t->batch_size, K, H / 2), "dY re-layout (channel-last)");
+        if (!c->cur_dye_valid) ck(mid_cl_relayout_end(G.compute, dy, c->cur_dye, t->batch_size, K, H / 2), "dY re-layout (channel-last)");
         c->cur_dye_valid = 1;
         ck(mid_cl_dgrad2(G.compute, c->cur_dye, we->dgrad, dx, t->batch_size, C, H, K), "convolution dgrad (bf16, channel-last, stride 2)");
         c->fz_req_valid = 0;
@@ -970,6 +970,12 @@ static void unit_bwd(Train_ResNet *t, const float *in, const float *w, const Bat
     } else
     ck(mid_bn_bwd_t(G.compute, c->bn_ws, conv_out, x_dt, bn->gamma, bn->beta, cache->means, cache->vars, dy, mask_src, gated_out, c->dtype,
                     d_conv_out, dbn->gamma, dbn->beta, N, K, Ho * Ho, t->eps, mask_mode), "batch norm backward");
+    if (c->dtype == MID_BF16 && !stem && stride == 2 && k == 3 && c->cur_dye && !c->cur_dye_valid) {
+        /* the channel-last copy of d_conv_out that the stride-2 dgrad AND the weight gradient read: made here, before either is
+         * launched, so that every weight-gradient schedule (the free-running one starts before the dgrad) runs the same kernels */
+        ck(mid_cl_relayout_end(G.compute, d_conv_out, c->cur_dye, N, K, Ho), "dY re-layout (channel-last)");
+        c->cur_dye_valid = 1;
+    }
     if (c->overlap_wgrad == 2 && d_slot >= 0) {
         /* d_conv_out is final once BN' is: the weight gradient may start now and run for as long as the slot lives */
         mid_event_record(c->ev_bn_done, G.compute);
