@@ -79,6 +79,7 @@ typedef struct MiCtx {
      * fills fz_req before the unit whose dgrad should do it; the unit's dgrad moves it to fz_done (nparts > 0) for the next unit_bwd */
     mid_bn_bwd_parts fz_req, fz_done;
     int cl_wgrad2;               /* bf16: stride-2 weight gradients with both operands channel-last where the plane does not fill 64-pixel tiles (RESNET_MI_BF16_CL_WGRAD2=0: off) */
+    int fz_bf16;                 /* bf16: which dgrads carry a BN' reduction (sites 1 | 2 | 4 as fz_f32; RESNET_MI_BF16_BNFUSE_SITES, default all) */
     int fz_req_valid, fz_ready, fz_enable, fz_f32; /* fz_f32: the fp32 dgrads do it too (RESNET_MI_F32_BNFUSE_BWD, default on) */
     float *stem_dx;              /* bf16 mode: the stem convolution's output gradient stays fp32 */
     void *stem_xp; size_t stem_xp_bytes;           /* bf16 mode: the batch as zero-padded bf16 parity planes (kernels_stem_bf16.hip) */

@@ -545,6 +545,7 @@ Train_ResNet *init_trainer(ResNet *model, Batch *cur_batch, int batch_size, floa
      * keeps lane = column, so the fused form reads x / mask / addend with 4-byte accesses (four times the memory instructions of the
      * bf16 kernel's row-major drain) and pays for it wherever the separate reduction pass was only 2 tensors; site 4 replaces a
      * 4-tensor pass and breaks even, so it is the default */
+    c->fz_bf16 = getenv("RESNET_MI_BF16_BNFUSE_SITES") ? atoi(getenv("RESNET_MI_BF16_BNFUSE_SITES")) : 7;
     c->cl_wgrad2 = !(getenv("RESNET_MI_BF16_CL_WGRAD2") && atoi(getenv("RESNET_MI_BF16_CL_WGRAD2")) == 0);
     c->fz_f32 = mid_igemm_mode() >= 2 ? (getenv("RESNET_MI_F32_BNFUSE_BWD") ? atoi(getenv("RESNET_MI_F32_BNFUSE_BWD")) : 4) : 0;
     c->overlap_wgrad = getenv("RESNET_MI_OVERLAP") ? atoi(getenv("RESNET_MI_OVERLAP")) : 1;
@@ -922,6 +923,11 @@ static void conv_dgrad_t(Train_ResNet *t, const float *w, const float *dy, float
         c->ws.pre_dgrad = NULL;
         return;
     }
+    {
+        static int minp = -1; /* diagnostic: RESNET_MI_BNFUSE_MINP = smallest plane (pixels) whose dgrad still carries the BN' reduction */
+        if (minp < 0) minp = getenv("RESNET_MI_BNFUSE_MINP") ? atoi(getenv("RESNET_MI_BNFUSE_MINP")) : 0;
+        if (c->fz_req_valid && H * H < minp) c->fz_req_valid = 0;
+    }
     if (c->dtype == MID_BF16 && c->fz_req_valid) { /* ... and the reduction pass of the BN' its output feeds */
         ck(mid_conv_dgrad_bn_bf16(G.compute, &c->ws, w, dy, dx, addend, t->batch_size, C, H, K, k, stride, &c->fz_req), "convolution dgrad + BN' reduction (bf16)");
         if (c->fz_req.nparts > 0) { c->fz_done = c->fz_req; c->fz_ready = 1; }
@@ -1045,7 +1051,7 @@ void backwards_pass(Train_ResNet *t) {
         /* (RECOMPUTE_BN: the gating tensors have just been re-derived when the dgrad runs.)  fp32 storage: not with the FULL policy
          * (its derivative mirror keeps the ungated gradients the dump tree names) */
         const int fz = c->fz_enable && (c->dtype == MID_BF16 || (c->fz_f32 && c->policy != MI_STORE_FULL));
-#define FZ_REQ(site_, x_, mask_, means_) do { if (fz && (c->dtype == MID_BF16 || (c->fz_f32 & (site_)))) { c->fz_req.x = (x_); c->fz_req.mask = (mask_); c->fz_req.means = (means_); \
+#define FZ_REQ(site_, x_, mask_, means_) do { if (fz && (c->dtype == MID_BF16 ? (c->fz_bf16 & (site_)) : (c->fz_f32 & (site_)))) { c->fz_req.x = (x_); c->fz_req.mask = (mask_); c->fz_req.means = (means_); \
         c->fz_req.buf = c->bn_parts.buf; c->fz_req.floats = c->bn_parts.floats; c->fz_req.nparts = 0; c->fz_req_valid = 1; } } while (0)
         const int up_gated = c->fz_ready; /* the block above's reduction dgrad already gated `up` by this block's output and summed for the expansion BN' */
         if (b->projection) {
