@@ -158,8 +158,11 @@ def launch_workers(args, argv):
         out = subprocess.PIPE if w["rank"] == 0 else subprocess.DEVNULL
         procs.append(subprocess.Popen(w["cmd"], env=dict(os.environ, **w["env"]), stdout=out))
     line, rc = "", 0
+    chunks = []
+    import threading
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)  # (a blocking read here would never
+    reader.start()                                                                                # see another rank fail)
     try:
-        line = procs[0].stdout.read().decode()
         pending = list(procs)
         while pending:
             for pr in list(pending):
@@ -176,6 +179,8 @@ def launch_workers(args, argv):
         for pr in procs:
             if pr.poll() is None:
                 pr.kill()
+    reader.join(timeout=10)
+    line = b"".join(chunks).decode()
     if rc == 0:
         sys.stdout.write(line)
         sys.stdout.flush()

@@ -169,6 +169,30 @@ def test_dp_bucket_plan_more_cuts_than_event_slots():
     assert plan[-1][1] - plan[-1][0] > plan[-2][1] - plan[-2][0]  # the merged tail: several blocks + the stem
 
 
+def test_bench_self_launch_notices_a_failed_rank(monkeypatch, capsys):
+    """the launcher of a bare `bench.py --gpus N`: a rank that dies must end the launch with ITS exit code while rank 0 is still
+    blocked (in a real run: in a collective, waiting for the dead peer) -- the other ranks are terminated, nothing is printed;
+    when every rank succeeds, rank 0's line is passed on unchanged"""
+    import time
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    py = sys.executable
+    args = types.SimpleNamespace(launch_dry_run=False, gpus=2)
+    monkeypatch.setattr(bench, "worker_plan", lambda a, v: [
+        {"rank": 0, "cmd": [py, "-c", "import time; time.sleep(120)"], "env": {}},
+        {"rank": 1, "cmd": [py, "-c", "import sys; sys.exit(3)"], "env": {}}])
+    t0 = time.time()
+    assert bench.launch_workers(args, []) == 3
+    assert time.time() - t0 < 30
+    assert capsys.readouterr().out == ""
+    monkeypatch.setattr(bench, "worker_plan", lambda a, v: [
+        {"rank": 0, "cmd": [py, "-c", "print('{\"value\": 1}')"], "env": {}},
+        {"rank": 1, "cmd": [py, "-c", "pass"], "env": {}}])
+    assert bench.launch_workers(args, []) == 0
+    assert capsys.readouterr().out.strip() == '{"value": 1}'
+
+
 def test_bench_self_launch_dry_run():
     """`python bench.py --gpus N` with no launcher around it starts N fresh rank processes itself BEFORE anything touches a GPU
     (the library is not even loaded in the parent).  --launch-dry-run prints what it would start: N workers running this script
