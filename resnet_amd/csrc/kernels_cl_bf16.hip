@@ -1281,6 +1281,32 @@ int mid_cl_fwd(mid_stream s, const void *xp, const void *a_tiles, void *y, int N
     return cl_launch((hipStream_t)s, (const u16 *)a_tiles, (const u16 *)xp, (u16 *)y, g, N, 2.0 * 9 * (double)N * g.P * C * K,
                      2.0 * ((double)N * C * H * H + (double)N * g.P * K) + 4.0 * 9 * C * K);
 }
+/* 1x1 convolution on a DENSE channel-last input ([N * H * H][C], mid_cl_relayout_dense): the same kernel with one tap -- both operands
+ * reduction-contiguous, nothing to transpose.  The form every 1x1 layer takes once activations are kept channel-last (DESIGN.md, next
+ * round); here an operator, to measure that claim on the benchmark's shapes. */
+int mid_cl_pw_supported(int N, int C, int H, int K) {
+    if (C % 64 || K % 64 || H < 2 || H > 240) return 0;
+    if ((double)N * H * H * C * 2 >= 4294000000.0 || (double)N * K * H * H >= 2147480000.0) return 0;
+    return 1;
+}
+int mid_cl_relayout_dense(mid_stream s, const void *x, void *xp, int N, int C, int H) {
+    hipLaunchKernelGGL(cl_relayout64_kernel, dim3(C / 64, mi_cdiv(H * H, 64), N), dim3(256), 0, (hipStream_t)s, (const u16 *)x, (u16 *)xp, C, H * H, H, H, H, 0, 0, make_fastdiv(H));
+    MI_LAUNCH_CHECK("cl_relayout64_kernel");
+    return 0;
+}
+int mid_cl_pw_fwd(mid_stream s, const void *xc, const void *a_tiles, void *y, int N, int C, int H, int K, mid_bn_parts *parts) {
+    if (parts) parts->nparts = 0;
+    if (!mid_cl_pw_supported(N, C, H, K)) { mi_record_error("mid_cl_pw_fwd", "shape not covered"); return -2; }
+    ClArgs g = {};
+    g.Cin = C; g.M = K; g.GH = H; g.GW = H; g.P = H * H; g.ntaps = 1;
+    g.img_rows = H; g.Wp = H;
+    g.tap_delta[0] = 0; g.tap_w[0] = 0;
+    const int bn = K % 128 == 0 ? 128 : 256;
+    const int ctl = mi_cdiv(N * g.P, bn);
+    if (parts && parts->buf && parts->floats >= (size_t)3 * ctl * (bn / 64) * K) { g.bn_part = parts->buf; parts->nparts = ctl * (bn / 64); }
+    return cl_launch((hipStream_t)s, (const u16 *)a_tiles, (const u16 *)xc, (u16 *)y, g, N, 2.0 * (double)N * g.P * C * K,
+                     2.0 * ((double)N * C * g.P + (double)N * g.P * K) + 4.0 * C * K);
+}
 /* dx (bf16 NCHW, C channels) = the stride-1 dgrad of dyp = dY re-laid with a halo of 1 (K channels), a_tiles = the dgrad k-step tiles
  * [t][k/64][C][64]; addend (optional, bf16 NCHW like dx; may be dx itself): added before the one rounding */
 int mid_cl_dgrad(mid_stream s, const void *dyp, const void *a_tiles, void *dx, const void *addend, int N, int C, int H, int K) {

@@ -334,6 +334,20 @@ int mi_op_conv_fwd_bf16_cl(const void *x, const float *w, void *y, int N, int C,
     mid_free(xp); mid_free(at);
     return rc;
 }
+/* 1x1 forward with the input re-laid dense channel-last (one tap of the channel-last kernel: both operands reduction-contiguous) */
+int mi_op_conv1x1_fwd_bf16_cl(const void *x, const float *w, void *y, int N, int C, int H, int K) {
+    if (!mid_cl_pw_supported(N, C, H, K)) return -2;
+    mid_stream st = mi_global()->compute;
+    const size_t xb = (size_t)N * H * H * C * 2 + 4096;
+    void *xp = mid_malloc(xb), *at = mid_malloc((size_t)C * K * 2);
+    if (!xp || !at) { mid_free(xp); mid_free(at); return -3; }
+    int rc = mid_bf16_prelayout_fwd(st, w, at, K, C, 1);
+    if (!rc) rc = mid_cl_relayout_dense(st, x, xp, N, C, H);
+    if (!rc) rc = mid_cl_pw_fwd(st, xp, at, y, N, C, H, K, NULL);
+    rc = finish(rc);
+    mid_free(xp); mid_free(at);
+    return rc;
+}
 int mi_op_conv_dgrad_bf16_cl(const float *w, const void *dy, void *dx, int N, int C, int H, int K, int stride, int to_add) {
     if (stride == 2) {
         if (to_add || !mid_cl_dgrad2_supported(N, C, H, K)) return -2;

@@ -223,6 +223,15 @@ class Ops:
         self._chk(self.L.mi_op_conv_wgrad_bf16_cl(dx.ptr, ddy.ptr, dw.ptr, N, Cc, H, K, stride), "conv_wgrad_bf16_cl")
         return dw.get()
 
+    def conv1x1_fwd_bf16_cl(self, x, w):
+        N, Cc, H, _ = x.shape
+        K = w.shape[0]
+        BF = B.MI_DTYPE_BF16
+        dx, dw = self.dev_t(x, BF), self.dev(w)
+        dy = self.new_t((N, K, H, H), BF)
+        self._chk(self.L.mi_op_conv1x1_fwd_bf16_cl(dx.ptr, dw.ptr, dy.ptr, N, Cc, H, K), "conv1x1_fwd_bf16_cl")
+        return self.get_t(dy, BF)
+
     def conv_wgrad_bf16_cl2(self, x, dy):
         """3x3 stride 2, both operands re-laid channel-last (cl_wgrad2_kernel)"""
         N, Cc, H, _ = x.shape

@@ -680,3 +680,17 @@ def test_conv_wgrad_s2_bf16_both_operands_channel_last(ops, oracle, shape):
     ref = oracle.conv_wgrad(x, dy, 3, 2)
     got = ops.conv_wgrad_bf16_cl2(nchw(x), nchw(dy))
     check_grad(got, ref, "channel-last (both operands) conv wgrad %s" % (shape,))
+
+
+PW_CL_SHAPES = [(1024, 14, 256, 3), (256, 14, 1024, 2), (2048, 7, 512, 5), (512, 7, 2048, 3), (128, 28, 512, 2), (64, 56, 256, 1), (256, 56, 64, 1), (64, 10, 192, 3)]
+
+
+@pytest.mark.parametrize("shape", PW_CL_SHAPES, ids=["C%d_H%d_K%d_N%d" % s for s in PW_CL_SHAPES])
+def test_conv1x1_fwd_bf16_on_dense_channel_last_input(ops, oracle, shape):
+    """the channel-last kernel with ONE tap on a dense [pixels][channels] input: the form a 1x1 layer takes once activations are kept
+    channel-last (both operands reduction-contiguous: LDS-DMA + plain ds_read_b128, planes of 49 / 196 pixels need no special case)"""
+    C, H, K, N = shape
+    x, w, _ = _conv_data(C, H, K, 1, 1, N)
+    ref = oracle.conv_fwd(x, bf16_round(w), 1)
+    got = ops.conv1x1_fwd_bf16_cl(nchw(x), w)
+    check_bf(nhwc(got), ref, "1x1 forward, channel-last input %s" % (shape,))
