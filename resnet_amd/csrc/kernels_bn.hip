@@ -223,6 +223,59 @@ bn_apply_kernel(const TX *__restrict__ x, const float *__restrict__ gamma, const
     }
 }
 
+// BN + ReLU of a bf16 NCHW tensor written TWICE: as NCHW (what every other consumer reads) and as the zero-padded channel-last plane
+// [N][H+2][W+2][C] the channel-last 3x3 kernels take (kernels_cl_bf16.hip) -- the re-layout pass of its own (read T, write T) becomes
+// one extra write.  Tile = 64 channels x 64 pixels of one image, transposed through LDS; the arithmetic is bn_apply_kernel's.
+typedef uint32_t bn_u32x4 __attribute__((ext_vector_type(4)));
+typedef bn_u32x4 __attribute__((aligned(2))) bn_u32x4_u2;
+__global__ void __launch_bounds__(256)
+bn_apply_cl_kernel(const bf16_t *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ means,
+                   const float *__restrict__ vars, bf16_t *__restrict__ y, bf16_t *__restrict__ ycl, int C, int P, int W, float eps, FastDiv fdW) {
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64 * 72];  // [pixel][64 channels], pitch 72
+    const int c0 = blockIdx.x * 64, p0 = blockIdx.y * 64, n = blockIdx.z;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int idx = threadIdx.x + 256 * u, cc = idx >> 3, part = idx & 7;
+        const int c = c0 + cc, pp = p0 + part * 8;
+        const float mean = means[c], sd = sqrtf(vars[c] + eps), g = gamma[c], b = beta[c];
+        const size_t e = ((size_t)n * C + c) * P + pp;
+        const int nv = min(8, P - pp);             // elements of this piece that lie in the plane (<= 0: none)
+        float v[8];
+        if (nv >= 8) {
+            const bn_u32x4 t = *(const bn_u32x4_u2 *)(x + e);
+#pragma unroll
+            for (int q = 0; q < 4; q++) { v[2 * q] = __uint_as_float(t[q] << 16); v[2 * q + 1] = __uint_as_float(t[q] & 0xffff0000u); }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[q] = q < nv ? mi_bf2f(x[e + q]) : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = fmaxf(bn_y(bn_xhat(v[q], mean, sd), g, b), 0.f);
+        const bn_u32x4 o = {mi_pack_bf2(v[0], v[1]), mi_pack_bf2(v[2], v[3]), mi_pack_bf2(v[4], v[5]), mi_pack_bf2(v[6], v[7])};
+        if (nv >= 8) *(bn_u32x4_u2 *)(y + e) = o;
+        else {
+#pragma unroll
+            for (int q = 0; q < 8; q++) if (q < nv) y[e + q] = (bf16_t)((q & 1) ? o[q >> 1] >> 16 : o[q >> 1] & 0xffffu);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            tile[(part * 8 + 2 * q) * 72 + cc] = (bf16_t)(o[q] & 0xffffu);
+            tile[(part * 8 + 2 * q + 1) * 72 + cc] = (bf16_t)(o[q] >> 16);
+        }
+    }
+    __syncthreads();
+    const int H = W;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int idx = threadIdx.x + 256 * u, px = idx >> 3, piece = idx & 7;
+        const int p = p0 + px;
+        if (p < P) {
+            const uint32_t yy = fd_div((uint32_t)p, fdW), xx = (uint32_t)p - yy * W;
+            *(bn_u32x4 *)(ycl + (((size_t)n * (H + 2) + yy + 1) * (W + 2) + xx + 1) * C + c0 + piece * 8) = *(const bn_u32x4 *)(tile + px * 72 + piece * 8);
+        }
+    }
+}
+
 // grid (C, nsplit): s1 = sum g, s2 = sum g * x_hat.  Same flattened (image, position) walk as bn_stats_kernel.
 // MASK 3 = MASK 2 (gate dy by mask_src > 0) that also WRITES the gated dy: the identity blocks need relu'(out) * upstream
 // twice more (BN' apply, shortcut addend of the 1x1 dgrad), and producing it here saves the separate ReLU' pass.
@@ -524,9 +577,23 @@ int mid_bn_debug_merge(mid_stream s, int R, int C, float *means, float *vars, fl
 /* (the bf16 kernels pad every image's columns to a multiple of 8) */
 size_t mid_bn_parts_floats(int N, int K, int Ho) { return (size_t)3 * (size_t)mi_cdiv((long)N * ((Ho * Ho + 7) / 8 * 8), 128) * 4 * K; }
 
+/* side output of the NEXT forward apply (one-shot: the caller sets it right before the call, the launcher consumes it): the activation
+ * also as a zero-padded channel-last plane of H x H pixels (bn_apply_cl_kernel) */
+static struct { void *out; int H; } g_bn_cl = {nullptr, 0};
+extern "C" void mid_bn_set_cl_out(void *ycl, int H) { g_bn_cl.out = ycl; g_bn_cl.H = H; }
 static int bn_fwd_apply(hipStream_t st, const void *x, int x_dt, const float *gamma, const float *beta, const void *residual,
                         const float *means, const float *vars, void *y, int a_dt, float *xhat_out, float *norm_out, int N, int C,
                         int P, float eps, int relu) {
+    void *ycl = g_bn_cl.out;
+    const int Hcl = g_bn_cl.H;
+    g_bn_cl.out = nullptr;
+    if (ycl && x_dt == MID_BF16 && a_dt == MID_BF16 && !residual && relu && !xhat_out && !norm_out && C % 64 == 0 && Hcl * Hcl == P) {
+        hipLaunchKernelGGL(bn_apply_cl_kernel, dim3(C / 64, mi_cdiv(P, 64), N), dim3(256), 0, st, (const bf16_t *)x, gamma, beta, means, vars, (bf16_t *)y,
+                           (bf16_t *)ycl, C, P, Hcl, eps, make_fastdiv(Hcl));
+        MI_LAUNCH_CHECK("bn_apply_cl_kernel");
+        return 0;
+    }
+    if (ycl) { mi_record_error("bn_fwd_apply", "channel-last side output requested for a form that has none"); return -2; }
     const size_t total = (size_t)N * C * P;
     const FastDiv fdP = make_fastdiv(P), fdC = make_fastdiv(C);
     bool str;

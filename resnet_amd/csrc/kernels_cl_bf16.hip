@@ -722,7 +722,7 @@ struct ClWg2Args {
     int R;                          // reduction length = N * GH * GW pixels
     int rtiles, rlen;               // 64-pixel tiles in all; per split
     int img_rows, Wp;               // parity-plane geometry of the input (as ClArgs)
-    uint32_t a_rowb, a_imgb;        // bytes of one dY plane row / one dY image ((Wo+1) K 2, (Ho+1)(Wo+1) K 2)
+    uint32_t a_rowb, a_imgb, a_off; // bytes of one dY plane row / one dY image; byte offset of pixel (0, 0) in a plane (stride 1: halo of 1)
     int ctiles, mtiles;
     uint32_t tap_delta[9];
     FastDiv fdGW, fdP, fdM, fdT, fd9;
@@ -774,7 +774,7 @@ cl_wgrad2_kernel(const u16 *__restrict__ dYc, const u16 *__restrict__ Xc, float 
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const bool ok = ld_j0 + brow + 16 * u < g.R;
-            const unsigned char *sa = (const unsigned char *)dYc + (rn[u] * g.a_imgb + ry[u] * g.a_rowb + rx[u] * acolb + (uint32_t)m0 * 2u + lanec[u]);
+            const unsigned char *sa = (const unsigned char *)dYc + (rn[u] * g.a_imgb + ry[u] * g.a_rowb + rx[u] * acolb + g.a_off + (uint32_t)m0 * 2u + lanec[u]);
             const unsigned char *sb = (const unsigned char *)Xc + (rn[u] * imgb + ry[u] * rowb + rx[u] * colb + tdelta + lanec[u]);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ok ? sa : (const unsigned char *)g.zero),
                                              (__attribute__((address_space(3))) void *)(la + u * 4096), 16, 0, 0);
@@ -1162,28 +1162,37 @@ static int cl_wgrad2_splits(int N, int C, int K, int P) {
     }
     return best;
 }
-/* weight gradient of a 3x3 stride-2 layer from the channel-last planes of BOTH operands: xp = mid_cl_relayout(parity) of the input,
- * dyp = mid_cl_relayout_end of dY (what mid_cl_dgrad2 reads); C % 128, K % 128, any plane size */
-int mid_cl_wgrad2_supported(int N, int C, int H, int K) {
-    if (!mid_cl_supported(0, N, C, H, K, 2)) return 0;
+/* weight gradient of a 3x3 layer from the channel-last planes of BOTH operands.  stride 2: xp = mid_cl_relayout(parity) of the input,
+ * dyp = mid_cl_relayout_end of dY (what mid_cl_dgrad2 reads); stride 1: xp = the input with a halo of 1, dyp = dY with a halo of 1 (what
+ * mid_cl_dgrad reads).  C % 128, K % 128, any plane size */
+int mid_cl_wgrad2_supported(int N, int C, int H, int K, int stride) {
+    if (!mid_cl_supported(0, N, C, H, K, stride)) return 0;
     if (C % 128 || K % 128) return 0;
-    if ((double)N * (H / 2 + 1) * (H / 2 + 1) * K * 2 >= 4294000000.0 || (double)N * (H / 2) * (H / 2) + 64 >= 2147480000.0) return 0;
+    const int Ho = H / stride, Hq = stride == 2 ? Ho + 1 : Ho + 2;
+    if ((double)N * Hq * Hq * K * 2 >= 4294000000.0 || (double)N * Ho * Ho + 64 >= 2147480000.0) return 0;
     return 1;
 }
-size_t mid_cl_wgrad2_part_floats(int N, int C, int H, int K) { return (size_t)cl_wgrad2_splits(N, C, K, (H / 2) * (H / 2)) * 9 * K * C; }
-int mid_cl_wgrad2(mid_stream s, const void *xp, const void *dyp, float *dw, float *part, size_t part_floats, int N, int C, int H, int K) {
+size_t mid_cl_wgrad2_part_floats(int N, int C, int H, int K, int stride) { return (size_t)cl_wgrad2_splits(N, C, K, (H / stride) * (H / stride)) * 9 * K * C; }
+int mid_cl_wgrad2(mid_stream s, const void *xp, const void *dyp, float *dw, float *part, size_t part_floats, int N, int C, int H, int K, int stride) {
     hipStream_t st = (hipStream_t)s;
-    if (!mid_cl_wgrad2_supported(N, C, H, K)) { mi_record_error("mid_cl_wgrad2", "shape not covered"); return -2; }
+    if (!mid_cl_wgrad2_supported(N, C, H, K, stride)) { mi_record_error("mid_cl_wgrad2", "shape not covered"); return -2; }
     if (cl_zero_page("mid_cl_wgrad2")) return -1;
     ClWg2Args g = {};
-    g.K = K; g.C = C; g.GH = H / 2; g.GW = H / 2; g.R = N * g.GH * g.GW;
-    const int Hp = g.GW + 1;
-    g.img_rows = 4 * Hp; g.Wp = Hp;
-    for (int t = 0; t < 9; t++) {
-        const int r = t / 3, sx = t % 3, q = 2 * ((r + 1) & 1) + ((sx + 1) & 1);
-        g.tap_delta[t] = (uint32_t)(((q * Hp + (r > 0)) * Hp + (sx > 0)) * C) * 2u;
+    g.K = K; g.C = C; g.GH = H / stride; g.GW = H / stride; g.R = N * g.GH * g.GW;
+    if (stride == 2) {
+        const int Hp = g.GW + 1;
+        g.img_rows = 4 * Hp; g.Wp = Hp;
+        for (int t = 0; t < 9; t++) {
+            const int r = t / 3, sx = t % 3, q = 2 * ((r + 1) & 1) + ((sx + 1) & 1);
+            g.tap_delta[t] = (uint32_t)(((q * Hp + (r > 0)) * Hp + (sx > 0)) * C) * 2u;
+        }
+        g.a_rowb = (uint32_t)Hp * K * 2u; g.a_imgb = (uint32_t)Hp * g.a_rowb; g.a_off = 0;
+    } else {
+        const int Hp = H + 2;
+        g.img_rows = Hp; g.Wp = Hp;
+        for (int t = 0; t < 9; t++) g.tap_delta[t] = (uint32_t)(((t / 3) * Hp + (t % 3)) * C) * 2u;
+        g.a_rowb = (uint32_t)Hp * K * 2u; g.a_imgb = (uint32_t)Hp * g.a_rowb; g.a_off = g.a_rowb + (uint32_t)K * 2u;
     }
-    g.a_rowb = (uint32_t)Hp * K * 2u; g.a_imgb = (uint32_t)Hp * g.a_rowb;
     g.rtiles = mi_cdiv(g.R, 64);
     const int splits = cl_wgrad2_splits(N, C, K, g.GH * g.GW);
     if (part_floats < (size_t)splits * 9 * K * C) { mi_record_error("mid_cl_wgrad2", "workspace too small"); return -3; }

@@ -49,6 +49,8 @@ typedef struct {
     /* the stride-2 dgrads' output gradient re-laid channel-last with a zero row / column at the far end (kernels_cl_bf16.hip); the
      * halo is zeroed once, when the buffers are made; NULL = that layer's dgrad stays on the NCHW kernel */
     void *dye_spatial, *dye_proj;
+    void *dy1;                   /* stride-1 blocks: the 3x3's output gradient as a zero-padded channel-last plane (re-laid once per backward pass: dgrad and weight gradient read it) */
+    void *cl_s1;                 /* stride-1 blocks: the 3x3's input as ONE zero-padded channel-last plane, written by the reduction BN's apply itself */
     void *cl_spatial, *cl_proj;  /* channel-last parity planes of the layer's input: forward + weight gradient (kernels_cl_bf16.hip) */
 } MiParity;
 typedef struct MiCtx {
@@ -78,6 +80,7 @@ typedef struct MiCtx {
     /* bf16: the reduction pass of a unit's BN' done by the dgrad that produces its dy (mid_conv_dgrad_bn_bf16).  backwards_pass
      * fills fz_req before the unit whose dgrad should do it; the unit's dgrad moves it to fz_done (nparts > 0) for the next unit_bwd */
     mid_bn_bwd_parts fz_req, fz_done;
+    void *bn_cl_out; int bn_cl_H; /* forward: the next unit's BN apply also writes this channel-last plane (stride-1 3x3 input), or NULL */
     int cl_wgrad2;               /* bf16: stride-2 weight gradients with both operands channel-last where the plane does not fill 64-pixel tiles (RESNET_MI_BF16_CL_WGRAD2=0: off) */
     int fz_bf16;                 /* bf16: which dgrads carry a BN' reduction (sites 1 | 2 | 4 as fz_f32; RESNET_MI_BF16_BNFUSE_SITES, default all) */
     int fz_req_valid, fz_ready, fz_enable, fz_f32; /* fz_f32: the fp32 dgrads do it too (RESNET_MI_F32_BNFUSE_BWD, default on) */

@@ -377,20 +377,22 @@ int mi_op_conv_dgrad_bf16_cl(const float *w, const void *dy, void *dx, int N, in
     return rc;
 }
 
-/* 3x3 stride-2 weight gradient from the channel-last planes of BOTH operands (cl_wgrad2_kernel): the input's parity planes and the dY
- * planes of the stride-2 dgrad */
-int mi_op_conv_wgrad_bf16_cl2(const void *x, const void *dy, float *dw, int N, int C, int H, int K) {
-    if (!mid_cl_wgrad2_supported(N, C, H, K)) return -2;
+/* 3x3 weight gradient from the channel-last planes of BOTH operands (cl_wgrad2_kernel): stride 2 = the input's parity planes and the dY
+ * planes of the stride-2 dgrad; stride 1 = both with a halo of 1 */
+int mi_op_conv_wgrad_bf16_cl2(const void *x, const void *dy, float *dw, int N, int C, int H, int K, int stride) {
+    if (!mid_cl_wgrad2_supported(N, C, H, K, stride)) return -2;
     mid_stream st = mi_global()->compute;
-    const size_t xb = mid_cl_operand_bytes(0, N, C, H, K, 2), yb = mid_cl_dgrad2_operand_bytes(N, K, H / 2), pf = mid_cl_wgrad2_part_floats(N, C, H, K);
+    const int Ho = H / stride;
+    const size_t xb = mid_cl_operand_bytes(0, N, C, H, K, stride), yb = stride == 2 ? mid_cl_dgrad2_operand_bytes(N, K, Ho) : mid_cl_operand_bytes(1, N, C, H, K, 1),
+                 pf = mid_cl_wgrad2_part_floats(N, C, H, K, stride);
     void *xp = mid_malloc(xb), *dyp = mid_malloc(yb);
     float *part = (float *)mid_malloc(pf * sizeof(float));
     if (!xp || !dyp || !part) { mid_free(xp); mid_free(dyp); mid_free(part); return -3; }
     mid_memset(xp, 0, xb, st);
     mid_memset(dyp, 0, yb, st);
-    int rc = mid_cl_relayout(st, x, xp, N, C, H, 1);
-    if (!rc) rc = mid_cl_relayout_end(st, dy, dyp, N, K, H / 2);
-    if (!rc) rc = mid_cl_wgrad2(st, xp, dyp, dw, part, pf, N, C, H, K);
+    int rc = mid_cl_relayout(st, x, xp, N, C, H, stride == 2);
+    if (!rc) rc = stride == 2 ? mid_cl_relayout_end(st, dy, dyp, N, K, Ho) : mid_cl_relayout(st, dy, dyp, N, K, H, 0);
+    if (!rc) rc = mid_cl_wgrad2(st, xp, dyp, dw, part, pf, N, C, H, K, stride);
     rc = finish(rc);
     mid_free(xp); mid_free(dyp); mid_free(part);
     return rc;

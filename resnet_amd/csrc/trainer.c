@@ -341,7 +341,7 @@ static void size_workspaces(MiCtx *c, const Dims *d, ConvBlock **blocks, int N) 
         size_t a_ = mid_conv_ws_wt_floats(C_, K_, k_), b_ = mid_conv_ws_part_floats(N, C_, H_, K_, k_, s_); \
         if (c->dtype == MID_BF16 && (k_) <= 3) { size_t e_ = mid_bf16_part_floats(N, C_, H_, K_, k_, s_); if (e_ > b_) b_ = e_; } \
         if (c->dtype == MID_BF16 && (k_) == 3 && mid_cl_wgrad_supported(N, C_, H_, K_, s_)) { size_t e_ = mid_cl_wgrad_part_floats(N, C_, H_, K_, s_); if (e_ > b_) b_ = e_; } \
-        if (c->dtype == MID_BF16 && (k_) == 3 && (s_) == 2 && mid_cl_wgrad2_supported(N, C_, H_, K_)) { size_t e_ = mid_cl_wgrad2_part_floats(N, C_, H_, K_); if (e_ > b_) b_ = e_; } \
+        if (c->dtype == MID_BF16 && (k_) == 3 && mid_cl_wgrad2_supported(N, C_, H_, K_, s_)) { size_t e_ = mid_cl_wgrad2_part_floats(N, C_, H_, K_, s_); if (e_ > b_) b_ = e_; } \
         if (a_ > wt) wt = a_;                                                                 \
         if (b_ > part) part = b_;                                                             \
         if ((K_) > maxc) maxc = (K_);                                                         \
@@ -364,7 +364,23 @@ static void size_workspaces(MiCtx *c, const Dims *d, ConvBlock **blocks, int N) 
         c->par = (MiParity *)calloc((size_t)(d->n_conv_blocks > 0 ? d->n_conv_blocks : 1), sizeof(MiParity));
         for (int i = 0; i < d->n_conv_blocks; i++) {
             const ConvBlock *b = blocks[i];
-            if (b->stride != 2) continue;
+            if (b->stride != 2) {
+                /* stride-1 3x3: forward and weight gradient on the channel-last plane the reduction BN writes beside its NCHW output
+                 * (RESNET_MI_BF16_CL_S1=0: the NCHW kernels) */
+                const int Hs = b->incoming_spatial_dim;
+                if (!(getenv("RESNET_MI_BF16_CL_S1") && atoi(getenv("RESNET_MI_BF16_CL_S1")) == 0) && mid_cl_supported(0, N, b->reduced_depth, Hs, b->reduced_depth, 1)) {
+                    const size_t by = mid_cl_operand_bytes(0, N, b->reduced_depth, Hs, b->reduced_depth, 1);
+                    c->par[i].cl_s1 = mi_ctx_alloc(c, by);
+                    mid_memset(c->par[i].cl_s1, 0, by, G.compute);
+                    if (!(getenv("RESNET_MI_BF16_CL_S1_DGRAD") && atoi(getenv("RESNET_MI_BF16_CL_S1_DGRAD")) == 0) &&
+                        mid_cl_supported(1, N, b->reduced_depth, Hs, b->reduced_depth, 1)) {
+                        const size_t dyb = mid_cl_operand_bytes(1, N, b->reduced_depth, Hs, b->reduced_depth, 1);
+                        c->par[i].dy1 = mi_ctx_alloc(c, dyb);
+                        mid_memset(c->par[i].dy1, 0, dyb, G.compute);
+                    }
+                }
+                continue;
+            }
             const size_t H = b->incoming_spatial_dim, e1 = (size_t)N * b->reduced_depth * H * H, e2 = (size_t)N * b->incoming_filters * H * H;
             /* forward and weight gradient on channel-last parity planes (RESNET_MI_BF16_CL_S2=0: the NCHW kernels and their planes) */
             int need_sp = 1, need_pr = b->projection != NULL;
@@ -373,13 +389,13 @@ static void size_workspaces(MiCtx *c, const Dims *d, ConvBlock **blocks, int N) 
                     const size_t by = mid_cl_operand_bytes(0, N, b->reduced_depth, (int)H, b->reduced_depth, 2);
                     c->par[i].cl_spatial = mi_ctx_alloc(c, by);
                     mid_memset(c->par[i].cl_spatial, 0, by, G.compute); /* the halo stays zero: the re-layout writes the interior only */
-                    need_sp = !mid_cl_wgrad_supported(N, b->reduced_depth, (int)H, b->reduced_depth, 2) && !mid_cl_wgrad2_supported(N, b->reduced_depth, (int)H, b->reduced_depth);
+                    need_sp = !mid_cl_wgrad_supported(N, b->reduced_depth, (int)H, b->reduced_depth, 2) && !mid_cl_wgrad2_supported(N, b->reduced_depth, (int)H, b->reduced_depth, 2);
                 }
                 if (b->projection && mid_cl_supported(0, N, b->incoming_filters, (int)H, b->expanded_depth, 2)) {
                     const size_t by = mid_cl_operand_bytes(0, N, b->incoming_filters, (int)H, b->expanded_depth, 2);
                     c->par[i].cl_proj = mi_ctx_alloc(c, by);
                     mid_memset(c->par[i].cl_proj, 0, by, G.compute);
-                    need_pr = !mid_cl_wgrad_supported(N, b->incoming_filters, (int)H, b->expanded_depth, 2) && !mid_cl_wgrad2_supported(N, b->incoming_filters, (int)H, b->expanded_depth);
+                    need_pr = !mid_cl_wgrad_supported(N, b->incoming_filters, (int)H, b->expanded_depth, 2) && !mid_cl_wgrad2_supported(N, b->incoming_filters, (int)H, b->expanded_depth, 2);
                 }
             }
             if (need_sp) { c->par[i].spatial_bytes = e1 * 2; c->par[i].spatial = (char *)mi_ctx_alloc(c, e1 * 2 + 2 * MI_GUARD) + MI_GUARD; }
@@ -797,6 +813,9 @@ static void unit_fwd(Train_ResNet *t, const float *in, const float *w, const Bat
         parts = &c->bn_parts; /* (the stem's tensors are fp32 here, but its statistics still come from the kernel's accumulators) */
         ck(mid_stem_fwd_bf16(G.compute, in, w, conv_out, c->stem_xp, c->stem_xp_bytes, c->stem_scratch, c->stem_scratch_floats, N, H, parts),
            "stem convolution forward (bf16 operands)");
+    } else if (bf && k == 3 && stride == 1 && c->cur_cl && we && we->fwd) {
+        /* the reduction BN wrote this input as a zero-padded channel-last plane beside its NCHW output: no re-layout pass */
+        ck(mid_cl_fwd(G.compute, c->cur_cl, we->fwd, conv_out, N, C, H, K, 1, parts), "convolution forward (bf16, channel-last)");
     } else if (bf && k == 3 && stride == 2 && c->cur_cl && we && we->fwd) {
         /* channel-last route: the input re-laid once as four zero-padded parity planes, which the weight gradient reads again */
         ck(mid_cl_relayout(G.compute, in, c->cur_cl, N, C, H, 1), "input re-layout (channel-last parity planes)");
@@ -807,6 +826,7 @@ static void unit_fwd(Train_ResNet *t, const float *in, const float *w, const Bat
         if (stride == 2 && c->cur_par_valid) *c->cur_par_valid = c->ws.s2d_valid; /* the launch says whether it left the parity planes */
     } else ck(mid_conv_fwd_stats(G.compute, &c->ws, in, w, conv_out, N, C, H, K, k, stride, parts), "convolution forward");
     c->ws.pre_fwd = NULL;
+    if (c->bn_cl_out) { mid_bn_set_cl_out(bf ? c->bn_cl_out : NULL, c->bn_cl_H); c->bn_cl_out = NULL; }
     ck(mid_bn_fwd_t(G.compute, c->bn_ws, parts, conv_out, bf ? MID_BF16 : MID_F32, bn->gamma, bn->beta, residual, cache->means, cache->vars,
                     act_out, c->dtype, cache->normalized_temp, cache->normalized, N, K, Ho * Ho, t->eps, relu), "batch norm forward");
 }
@@ -839,10 +859,11 @@ void forward_pass(Train_ResNet *t) {
         const ConvBlock *b = p->conv_blocks[i];
         Activation_ConvBlock *k = a->activation_conv_blocks[i];
         const int H = b->incoming_spatial_dim, Ho = H / b->stride;
+        if (c->par && c->par[i].cl_s1) { c->bn_cl_out = c->par[i].cl_s1; c->bn_cl_H = H; }
         unit_fwd(t, bin, b->depth_reduction, b->norm_depth_reduction, k->norm_post_reduced, k->post_reduced,
                  k->post_reduced_activated, NULL, b->incoming_filters, H, b->reduced_depth, 1, 1, 1, 0);
         if (c->par) set_cur_par(c, c->par[i].spatial, c->par[i].spatial_bytes, &c->par[i].spatial_valid); else set_cur_par(c, NULL, 0, NULL);
-        c->cur_cl = c->par ? c->par[i].cl_spatial : NULL;
+        c->cur_cl = c->par ? (b->stride == 2 ? c->par[i].cl_spatial : c->par[i].cl_s1) : NULL;
         unit_fwd(t, k->post_reduced_activated, b->spatial, b->norm_spatial, k->norm_post_spatial, k->post_spatial,
                  k->post_spatial_activated, NULL, b->reduced_depth, H, b->reduced_depth, 3, b->stride, 1, 0);
         const float *res = bin;
@@ -913,6 +934,13 @@ static void conv_dgrad_t(Train_ResNet *t, const float *w, const float *dy, float
     MiCtx *c = ctx_of(t);
     const mid_wt_entry *we = wt_lookup(c, w);
     c->ws.pre_dgrad = we ? we->dgrad : NULL;
+    if (c->dtype == MID_BF16 && stride == 1 && k == 3 && c->cur_dye && c->cur_dye_valid && we && we->dgrad) {
+        /* stride-1 dgrad on the channel-last dY plane (the BN' below then runs its own reduction pass: measured neutral) */
+        ck(mid_cl_dgrad(G.compute, c->cur_dye, we->dgrad, dx, addend, t->batch_size, C, H, K), "convolution dgrad (bf16, channel-last)");
+        c->fz_req_valid = 0;
+        c->ws.pre_dgrad = NULL;
+        return;
+    }
     if (c->dtype == MID_BF16 && stride == 2 && k == 3 && !addend && c->cur_dye && we && we->dgrad) {
         /* stride-2 dgrad on channel-last dY: re-lay dY (K channels, H/2 x H/2) into the layer's zero-bordered buffer, then both column
          * parities of dx per workgroup by LDS-DMA staged MFMAs (dense stores; 1.5-1.9x the NCHW kernel's four parity classes) */
@@ -949,11 +977,13 @@ static void conv_wgrad_t(Train_ResNet *t, mid_stream st, const float *x, const f
         ck(mid_stem_wgrad_f32(st, c->stem_xp, dy, dw, c->stem_scratch, c->stem_scratch_floats, t->batch_size, H), "stem convolution wgrad (fp32 matrix cores)");
     else if (stem && c->stem_scratch) /* the forward pass left the batch as padded bf16 parity planes */
         ck(mid_stem_wgrad_bf16(st, c->stem_xp, dy, dw, c->stem_scratch, c->stem_scratch_floats, t->batch_size, H), "stem convolution wgrad (bf16 operands)");
-    else if (c->dtype == MID_BF16 && !stem && k == 3 && stride == 2 && c->cur_cl && c->cur_dye && c->cur_dye_valid && c->cl_wgrad2 &&
-             mid_cl_wgrad2_supported(t->batch_size, C, H, K) && (((H / 2) * (H / 2)) % 64 != 0 || !mid_cl_wgrad_supported(t->batch_size, C, H, K, 2)))
+    else if (c->dtype == MID_BF16 && !stem && k == 3 && c->cur_cl && c->cur_dye && c->cur_dye_valid && c->cl_wgrad2 &&
+             mid_cl_wgrad2_supported(t->batch_size, C, H, K, stride) && (((H / stride) * (H / stride)) % 64 != 0 || !mid_cl_wgrad_supported(t->batch_size, C, H, K, stride)))
         /* both operands channel-last (the dY planes the dgrad has just made): planes that do not fill 64-pixel tiles (784, 196, 49 pixels:
          * all of the benchmark network's stride-2 layers; -0.8 ms per step, most of it the two 7x7 layers the other kernel cannot take) */
-        ck(mid_cl_wgrad2(st, c->cur_cl, c->cur_dye, dw, c->ws.part, c->ws.part_floats, t->batch_size, C, H, K), "convolution wgrad (bf16, both operands channel-last)");
+        ck(mid_cl_wgrad2(st, c->cur_cl, c->cur_dye, dw, c->ws.part, c->ws.part_floats, t->batch_size, C, H, K, stride), "convolution wgrad (bf16, both operands channel-last)");
+    else if (c->dtype == MID_BF16 && !stem && k == 3 && stride == 1 && c->cur_cl && mid_cl_wgrad_supported(t->batch_size, C, H, K, 1))
+        ck(mid_cl_wgrad(st, c->cur_cl, dy, dw, c->ws.part, c->ws.part_floats, t->batch_size, C, H, K, 1), "convolution wgrad (bf16, channel-last input)");
     else if (c->dtype == MID_BF16 && !stem && k == 3 && stride == 2 && c->cur_cl && mid_cl_wgrad_supported(t->batch_size, C, H, K, 2))
         ck(mid_cl_wgrad(st, c->cur_cl, dy, dw, c->ws.part, c->ws.part_floats, t->batch_size, C, H, K, 2), "convolution wgrad (bf16, channel-last)");
     else if (c->dtype == MID_BF16 && !stem) ck(mid_conv_wgrad_bf16(st, &c->ws, x, dy, dw, t->batch_size, C, H, K, k, stride), "convolution wgrad (bf16)");
@@ -976,6 +1006,11 @@ static void unit_bwd(Train_ResNet *t, const float *in, const float *w, const Bat
     } else
     ck(mid_bn_bwd_t(G.compute, c->bn_ws, conv_out, x_dt, bn->gamma, bn->beta, cache->means, cache->vars, dy, mask_src, gated_out, c->dtype,
                     d_conv_out, dbn->gamma, dbn->beta, N, K, Ho * Ho, t->eps, mask_mode), "batch norm backward");
+    if (c->dtype == MID_BF16 && !stem && stride == 1 && k == 3 && c->cur_dye && !c->cur_dye_valid) {
+        /* stride 1: the same, one plane with a halo of 1 */
+        ck(mid_cl_relayout(G.compute, d_conv_out, c->cur_dye, N, K, Ho, 0), "dY re-layout (channel-last)");
+        c->cur_dye_valid = 1;
+    }
     if (c->dtype == MID_BF16 && !stem && stride == 2 && k == 3 && c->cur_dye && !c->cur_dye_valid) {
         /* the channel-last copy of d_conv_out that the stride-2 dgrad AND the weight gradient read: made here, before either is
          * launched, so that every weight-gradient schedule (the free-running one starts before the dgrad) runs the same kernels */
@@ -1086,8 +1121,8 @@ void backwards_pass(Train_ResNet *t) {
                               k->norm_post_reduced->means, k->norm_post_reduced->vars, k->post_reduced_activated, c->dtype, N, b->reduced_depth,
                               H * H, t->eps, 1), "BN recompute");
         if (c->par) set_cur_par(c, c->par[i].spatial, c->par[i].spatial_bytes, &c->par[i].spatial_valid); else set_cur_par(c, NULL, 0, NULL);
-        c->cur_dye = c->par ? c->par[i].dye_spatial : NULL;
-        c->cur_cl = c->par ? c->par[i].cl_spatial : NULL;
+        c->cur_dye = c->par ? (b->stride == 2 ? c->par[i].dye_spatial : c->par[i].dy1) : NULL;
+        c->cur_cl = c->par ? (b->stride == 2 ? c->par[i].cl_spatial : c->par[i].cl_s1) : NULL;
         FZ_REQ(2, k->post_reduced, k->post_reduced_activated, k->norm_post_reduced->means); /* spatial dgrad -> reduction BN' */
         unit_bwd(t, k->post_reduced_activated, b->spatial, b->norm_spatial, k->norm_post_spatial, db->norm_spatial,
                  k->post_spatial, dk->post_spatial_activated, NULL, 1, NULL, dk->post_spatial, s_spa, dk->post_reduced_activated, NULL,

@@ -232,14 +232,14 @@ class Ops:
         self._chk(self.L.mi_op_conv1x1_fwd_bf16_cl(dx.ptr, dw.ptr, dy.ptr, N, Cc, H, K), "conv1x1_fwd_bf16_cl")
         return self.get_t(dy, BF)
 
-    def conv_wgrad_bf16_cl2(self, x, dy):
-        """3x3 stride 2, both operands re-laid channel-last (cl_wgrad2_kernel)"""
+    def conv_wgrad_bf16_cl2(self, x, dy, stride=2):
+        """3x3, both operands re-laid channel-last (cl_wgrad2_kernel)"""
         N, Cc, H, _ = x.shape
         K = dy.shape[1]
         BF = B.MI_DTYPE_BF16
         dx, ddy = self.dev_t(x, BF), self.dev_t(dy, BF)
         dw = self.dev(shape=(K, Cc, 3, 3))
-        self._chk(self.L.mi_op_conv_wgrad_bf16_cl2(dx.ptr, ddy.ptr, dw.ptr, N, Cc, H, K), "conv_wgrad_bf16_cl2")
+        self._chk(self.L.mi_op_conv_wgrad_bf16_cl2(dx.ptr, ddy.ptr, dw.ptr, N, Cc, H, K, stride), "conv_wgrad_bf16_cl2")
         return dw.get()
 
     def conv_dgrad_bf16_cl(self, w, dy, H, dx_init=None, stride=1):

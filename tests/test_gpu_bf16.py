@@ -665,20 +665,20 @@ def test_conv_wgrad_bf16_channel_last(ops, oracle, shape):
     check_grad(got, ref, "channel-last conv wgrad %s" % (shape,))
 
 
-CL_WG2_SHAPES = [(512, 14, 512, 2), (1024, 14, 2048, 1), (128, 56, 128, 2), (256, 56, 512, 1), (512, 28, 1024, 3), (128, 8, 128, 4), (128, 12, 256, 3), (256, 6, 128, 5),
-                 (128, 4, 128, 7)]
+CL_WG2_SHAPES = [(512, 14, 512, 2, 2), (1024, 14, 2048, 2, 1), (128, 56, 128, 2, 2), (256, 56, 512, 2, 1), (512, 28, 1024, 2, 3), (128, 8, 128, 2, 4), (128, 12, 256, 2, 3),
+                 (256, 6, 128, 2, 5), (128, 4, 128, 2, 7), (128, 28, 128, 1, 3), (256, 14, 256, 1, 3), (512, 7, 512, 1, 5), (128, 8, 256, 1, 4), (128, 3, 128, 1, 6)]
 
 
-@pytest.mark.parametrize("shape", CL_WG2_SHAPES, ids=["C%d_H%d_K%d_N%d" % s for s in CL_WG2_SHAPES])
-def test_conv_wgrad_s2_bf16_both_operands_channel_last(ops, oracle, shape):
-    """cl_wgrad2_kernel: the stride-2 weight gradient from the input's parity planes and the channel-last dY planes of the stride-2 dgrad,
-    the reduction as ONE flat pixel list (tiles of 64 that straddle images: planes of 49, 196, 784, 16, 36, 9, 4 pixels), both fragments by
-    transposed LDS reads.  Same oracle and band as the NCHW kernel."""
-    C, H, K, N = shape
+@pytest.mark.parametrize("shape", CL_WG2_SHAPES, ids=["C%d_H%d_K%d_s%d_N%d" % s for s in CL_WG2_SHAPES])
+def test_conv_wgrad_bf16_both_operands_channel_last(ops, oracle, shape):
+    """cl_wgrad2_kernel: the weight gradient from channel-last planes of BOTH operands (stride 2: the input's parity planes and the dY planes
+    of the stride-2 dgrad; stride 1: both with a halo of 1), the reduction as ONE flat pixel list (tiles of 64 that straddle images: planes
+    of 49, 196, 784, 16, 36, 9, 4 pixels), both fragments by transposed LDS reads.  Same oracle and band as the NCHW kernel."""
+    C, H, K, stride, N = shape
     x = bf16_round(rand((N, H, H, C), 7))
-    dy = bf16_round(rand((N, H // 2, H // 2, K), 9))
-    ref = oracle.conv_wgrad(x, dy, 3, 2)
-    got = ops.conv_wgrad_bf16_cl2(nchw(x), nchw(dy))
+    dy = bf16_round(rand((N, H // stride, H // stride, K), 9))
+    ref = oracle.conv_wgrad(x, dy, 3, stride)
+    got = ops.conv_wgrad_bf16_cl2(nchw(x), nchw(dy), stride)
     check_grad(got, ref, "channel-last (both operands) conv wgrad %s" % (shape,))
 
 

@@ -34,8 +34,8 @@ for name, Cc, H, K, S in LAY:
     ops_ += [("wgrad nchw", lambda: L.mi_op_conv_wgrad_bf16(xb, yb, dw, N, Cc, H, K, 3, S))]
     if Cc % 128 == 0 and K % 128 == 0 and (Ho * Ho) % 4 == 0:
         ops_ += [("wgrad cl", lambda: L.mi_op_conv_wgrad_bf16_cl(xb, yb, dw, N, Cc, H, K, S))]
-    if S == 2 and Cc % 128 == 0 and K % 128 == 0:
-        ops_ += [("wgrad cl2", lambda: L.mi_op_conv_wgrad_bf16_cl2(xb, yb, dw, N, Cc, H, K))]
+    if Cc % 128 == 0 and K % 128 == 0:
+        ops_ += [("wgrad cl2", lambda: L.mi_op_conv_wgrad_bf16_cl2(xb, yb, dw, N, Cc, H, K, S))]
     for which, fn in ops_:
         L.mi_prof_enable(1)
         for rep in range(4):
