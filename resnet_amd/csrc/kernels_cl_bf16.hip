@@ -59,40 +59,14 @@ __device__ __forceinline__ float cl_bf2f(u16 v) { return __uint_as_float((uint32
 __device__ __forceinline__ int cl_key(int row) { return (row >> 1) & 7; }
 
 // x [N][C][H][W] bf16 -> channel-last, zero-padded (interior only: the halo is zeroed once, when the buffer is made).
-//   PAR = 0: one plane   Xc[n][y + yoff][x + xoff][c], Hp x Wp  (3x3 stride 1: yoff = xoff = 1, Hp = H + 2; dY of a stride-2 dgrad:
+//   par = 0: one plane   Xc[n][y + yoff][x + xoff][c], Hp x Wp  (3x3 stride 1: yoff = xoff = 1, Hp = H + 2; dY of a stride-2 dgrad:
 //            yoff = xoff = 0, Hp = H + 1 -- its taps look down / right)
-//   PAR = 1: four parity planes  Xp[n][2 pr + pc][a][b][c], Hp = H/2 + 1:  x[n][c][2 (a - 1) + pr][2 (b - 1) + pc]  (3x3 stride 2)
-// block = (64-channel chunk, input row or row pair, image): rows through LDS, out as 128-byte channel runs
-template <int PAR>
-__global__ void __launch_bounds__(256)
-cl_relayout_kernel(const u16 *__restrict__ x, u16 *__restrict__ xp, int C, int H, int W, int Hp, int Wp, int yoff, int xoff) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char cl_smem[];
-    u16 *tile = (u16 *)cl_smem;                   // [row of the block][x][64 channels], pitch 72 elements
-    constexpr int PT = 72;
-    const int c0 = blockIdx.x * 64, yb = blockIdx.y, n = blockIdx.z;
-    constexpr int RW = PAR ? 2 : 1;               // input rows per block
-    const int total = RW * 64 * W;
-    for (int e = threadIdx.x; e < total; e += 256) {
-        const int xx = e % W, t = e / W, cc = t & 63, rr = t >> 6;
-        tile[(rr * W + xx) * PT + cc] = x[(((size_t)n * C + c0 + cc) * H + RW * yb + rr) * W + xx];
-    }
-    __syncthreads();
-    const int pieces = RW * W * 8;                // (row, x, 16-byte piece of the 64 channels)
-    for (int e = threadIdx.x; e < pieces; e += 256) {
-        const int pc8 = e & 7, t = e >> 3, xx = t % W, rr = t / W;
-        const u32x4 v = *(const u32x4 *)(tile + (rr * W + xx) * PT + pc8 * 8);
-        size_t o;
-        if (PAR) o = ((((size_t)n * 4 + 2 * rr + (xx & 1)) * Hp + yb + 1) * Wp + (xx >> 1) + 1) * C;
-        else o = (((size_t)n * Hp + yb + yoff) * Wp + xx + xoff) * C;
-        *(u32x4 *)(xp + o + c0 + pc8 * 8) = v;
-    }
-}
-
-// The single-plane form again, tiled for the memory system: a block moves 64 channels x 64 consecutive pixels of one image -- in: 128-byte
+//   par = 1: four parity planes  Xp[n][2 pr + pc][a][b][c], Hp = H/2 + 1:  x[n][c][2 (a - 1) + pr][2 (b - 1) + pc]  (3x3 stride 2)
+// Tiled for the memory system: a block moves 64 channels x 64 consecutive pixels of one image -- in: 128-byte
 // runs of a channel plane (16-byte loads at any 2-byte alignment: gfx950 serves them at the streaming rate), out: 128-byte channel runs.
 typedef u32x4 __attribute__((aligned(2))) u32x4_u2;
 __global__ void __launch_bounds__(256)
-cl_relayout64_kernel(const u16 *__restrict__ x, u16 *__restrict__ xp, int C, int P, int W, int Hp, int Wp, int yoff, int xoff, FastDiv fdW) {
+cl_relayout64_kernel(const u16 *__restrict__ x, u16 *__restrict__ xp, int C, int P, int W, int Hp, int Wp, int yoff, int xoff, FastDiv fdW, int par) {
     __shared__ __attribute__((aligned(16))) u16 tile[64 * 72];  // [pixel][64 channels], pitch 72
     const int c0 = blockIdx.x * 64, p0 = blockIdx.y * 64, n = blockIdx.z;
 #pragma unroll
@@ -113,7 +87,10 @@ cl_relayout64_kernel(const u16 *__restrict__ x, u16 *__restrict__ xp, int C, int
         const int p = p0 + px;
         if (p < P) {
             const uint32_t y = fd_div((uint32_t)p, fdW), xx = (uint32_t)p - y * W;
-            *(u32x4 *)(xp + (((size_t)n * Hp + y + yoff) * Wp + xx + xoff) * C + c0 + piece * 8) = *(const u32x4 *)(tile + px * 72 + piece * 8);
+            // par: the four parity planes of a stride-2 forward (Hp = H / 2 + 1): plane 2 (y & 1) + (x & 1), row (y >> 1) + 1, column (x >> 1) + 1
+            const size_t o = par ? ((((size_t)n * 4 + 2 * (y & 1) + (xx & 1)) * Hp + (y >> 1) + 1) * Wp + (xx >> 1) + 1) * C
+                                 : (((size_t)n * Hp + y + yoff) * Wp + xx + xoff) * C;
+            *(u32x4 *)(xp + o + c0 + piece * 8) = *(const u32x4 *)(tile + px * 72 + piece * 8);
         }
     }
 }
@@ -1034,9 +1011,10 @@ int mid_cl_relayout(mid_stream s, const void *x, void *xp, int N, int C, int H, 
     mi_prof_begin((hipStream_t)s, MI_FAM_PCONV, 0.0, 4.0 * (double)N * C * H * H);
     if (parity) {
         const int Ho = H / 2;
-        hipLaunchKernelGGL(cl_relayout_kernel<1>, dim3(C / 64, Ho, N), dim3(256), (size_t)2 * H * 72 * 2, (hipStream_t)s, (const u16 *)x, (u16 *)xp, C, H, H, Ho + 1, Ho + 1, 0, 0);
+        // (the row-pair kernel cl_relayout_kernel<1> moved 3.0 TB/s; the 64 x 64 tile form with parity addressing on the way out does 3.8+)
+        hipLaunchKernelGGL(cl_relayout64_kernel, dim3(C / 64, mi_cdiv(H * H, 64), N), dim3(256), 0, (hipStream_t)s, (const u16 *)x, (u16 *)xp, C, H * H, H, Ho + 1, Ho + 1, 0, 0, make_fastdiv(H), 1);
     } else {
-        hipLaunchKernelGGL(cl_relayout64_kernel, dim3(C / 64, mi_cdiv(H * H, 64), N), dim3(256), 0, (hipStream_t)s, (const u16 *)x, (u16 *)xp, C, H * H, H, H + 2, H + 2, 1, 1, make_fastdiv(H));
+        hipLaunchKernelGGL(cl_relayout64_kernel, dim3(C / 64, mi_cdiv(H * H, 64), N), dim3(256), 0, (hipStream_t)s, (const u16 *)x, (u16 *)xp, C, H * H, H, H + 2, H + 2, 1, 1, make_fastdiv(H), 0);
     }
     mi_prof_end((hipStream_t)s);
     MI_LAUNCH_CHECK("cl_relayout_kernel");
@@ -1046,7 +1024,7 @@ int mid_cl_relayout(mid_stream s, const void *x, void *xp, int N, int C, int H, 
 int mid_cl_relayout_end(mid_stream s, const void *dy, void *dyp, int N, int K, int Ho) {
     mi_prof_begin((hipStream_t)s, MI_FAM_PCONV, 0.0, 4.0 * (double)N * K * Ho * Ho);
     hipLaunchKernelGGL(cl_relayout64_kernel, dim3(K / 64, mi_cdiv(Ho * Ho, 64), N), dim3(256), 0, (hipStream_t)s, (const u16 *)dy, (u16 *)dyp, K, Ho * Ho, Ho, Ho + 1, Ho + 1, 0, 0,
-                       make_fastdiv(Ho));
+                       make_fastdiv(Ho), 0);
     mi_prof_end((hipStream_t)s);
     MI_LAUNCH_CHECK("cl_relayout64_kernel");
     return 0;
@@ -1299,7 +1277,7 @@ int mid_cl_pw_supported(int N, int C, int H, int K) {
     return 1;
 }
 int mid_cl_relayout_dense(mid_stream s, const void *x, void *xp, int N, int C, int H) {
-    hipLaunchKernelGGL(cl_relayout64_kernel, dim3(C / 64, mi_cdiv(H * H, 64), N), dim3(256), 0, (hipStream_t)s, (const u16 *)x, (u16 *)xp, C, H * H, H, H, H, 0, 0, make_fastdiv(H));
+    hipLaunchKernelGGL(cl_relayout64_kernel, dim3(C / 64, mi_cdiv(H * H, 64), N), dim3(256), 0, (hipStream_t)s, (const u16 *)x, (u16 *)xp, C, H * H, H, H, H, 0, 0, make_fastdiv(H), 0);
     MI_LAUNCH_CHECK("cl_relayout64_kernel");
     return 0;
 }
