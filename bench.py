@@ -374,6 +374,7 @@ def main():
     if args.launch_dry_run:
         sys.exit(launch_workers(args, argv))
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it, and it must be there before HIP starts
     from resnet_amd import binding as B
     lib = B.load()
     if lib.mi_device_count() < 1:
