@@ -2,6 +2,7 @@
 struct layouts match the header, host-only entry points behave like the reference's, and the N>1 path's
 semantics (per-rank slices, per-replica BN, SUM of gradients) hold in a world_size-2 gloo run."""
 import ctypes as C
+import json
 import os
 import re
 import subprocess
@@ -191,6 +192,33 @@ def test_bench_self_launch_notices_a_failed_rank(monkeypatch, capsys):
         {"rank": 1, "cmd": [py, "-c", "pass"], "env": {}}])
     assert bench.launch_workers(args, []) == 0
     assert capsys.readouterr().out.strip() == '{"value": 1}'
+
+
+def test_bench_traffic_is_stamped_with_the_sources_it_was_measured_on(tmp_path, monkeypatch):
+    """roofline.traffic comes from committed rocprofv3 PMC passes; the record says which sources those were measured on and flags a
+    figure that belongs to an older build (bench.py cannot run the profiler on itself)"""
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    (tmp_path / "resnet_amd" / "csrc").mkdir(parents=True)
+    (tmp_path / "profiles").mkdir()
+    src = tmp_path / "resnet_amd" / "csrc" / "k.hip"
+    src.write_text("// kernel v1\n")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    sha1 = bench.source_sha16()
+    fam = {"hbm_GB_per_step_raw": 57.0}
+    (tmp_path / "profiles" / bench.PMC_FILE_F32).write_text(json.dumps({"source_sha16": sha1, "families": {bench.PMC_KEY[5]: fam}}))
+    leg = {"dom": 5, "dom_stats": (570, 600.0, 7.1e13, 1.7e11), "fam_stats": None, "fam_serial": None}
+    args = types.SimpleNamespace(steps=10)
+    roof = bench.roofline_of(leg, args, False)
+    assert roof["traffic"] == round(57.0e9 / 57) and roof["traffic_stale"] is False and "traffic_warning" not in roof
+    src.write_text("// kernel v2\n")                      # the kernels change, the PMC file does not
+    roof = bench.roofline_of(leg, args, False)
+    assert roof["traffic_stale"] is True and roof["traffic_source_sha16"] == sha1 and roof["current_source_sha16"] != sha1
+    assert "re-run tools/pmc_traffic.sh" in roof["traffic_warning"]
+    (tmp_path / "profiles" / bench.PMC_FILE_F32).unlink()   # no file: no figure, and the record says so
+    roof = bench.roofline_of(leg, args, False)
+    assert roof["traffic"] is None and "not present" in roof["traffic_note"]
 
 
 def test_bench_self_launch_dry_run():

@@ -17,8 +17,8 @@ def fam(name):
     if name.startswith("void igemm_kernel<") or name.startswith("void bgemm_kernel<"):
         ks = name.split("<")[1].split(",")[1].strip()
         return "igemm3x3" if ks == "3" else "gemm"
-    if "cl_conv_kernel" in name or "cl_dgrad2_kernel" in name or "cl_wgrad_kernel" in name: return "igemm3x3"   # channel-last 3x3 (bf16)
-    if "cl_relayout" in name or "bg_s2d" in name: return "igemm3x3_aux"
+    # channel-last 3x3 (bf16) and the re-layout passes bench.py brackets with that family (mid_cl_relayout*, bg_s2d)
+    if "cl_conv_kernel" in name or "cl_dgrad2_kernel" in name or "cl_wgrad" in name or "cl_relayout" in name or "bg_s2d" in name: return "igemm3x3"
     if "pw_wgrad_kernel" in name: return "gemm"
     if "bg_wt_" in name: return "igemm3x3_aux"
     if "igemm_tail_reduce" in name or "igemm_wt_kernel<9>" in name or "igemm_wgrad_reduce_kernel<9>" in name: return "igemm3x3_aux"
