@@ -581,12 +581,11 @@ size_t mid_bn_parts_floats(int N, int K, int Ho) { return (size_t)3 * (size_t)mi
  * also as a zero-padded channel-last plane of H x H pixels (bn_apply_cl_kernel) */
 static struct { void *out; int H; } g_bn_cl = {nullptr, 0};
 extern "C" void mid_bn_set_cl_out(void *ycl, int H) { g_bn_cl.out = ycl; g_bn_cl.H = H; }
+/* taken (and cleared) at the ENTRY of the public launchers, so that an early error return cannot leave it for some later layer */
+static void *bn_take_cl_out(int *H) { void *p = g_bn_cl.out; *H = g_bn_cl.H; g_bn_cl.out = nullptr; return p; }
 static int bn_fwd_apply(hipStream_t st, const void *x, int x_dt, const float *gamma, const float *beta, const void *residual,
                         const float *means, const float *vars, void *y, int a_dt, float *xhat_out, float *norm_out, int N, int C,
-                        int P, float eps, int relu) {
-    void *ycl = g_bn_cl.out;
-    const int Hcl = g_bn_cl.H;
-    g_bn_cl.out = nullptr;
+                        int P, float eps, int relu, void *ycl = nullptr, int Hcl = 0) {
     if (ycl && x_dt == MID_BF16 && a_dt == MID_BF16 && !residual && relu && !xhat_out && !norm_out && C % 64 == 0 && Hcl * Hcl == P) {
         hipLaunchKernelGGL(bn_apply_cl_kernel, dim3(C / 64, mi_cdiv(P, 64), N), dim3(256), 0, st, (const bf16_t *)x, gamma, beta, means, vars, (bf16_t *)y,
                            (bf16_t *)ycl, C, P, Hcl, eps, make_fastdiv(Hcl));
@@ -633,10 +632,12 @@ int mid_bn_stats_t(mid_stream s, float *ws, const void *x, int x_dt, float *mean
 /* y from x and GIVEN statistics (no reduction): forward's second half, and the backward-time recomputation of an activation */
 int mid_bn_apply_t(mid_stream s, const void *x, int x_dt, const float *gamma, const float *beta, const void *residual,
                    const float *means, const float *vars, void *y, int a_dt, int N, int C, int P, float eps, int relu) {
+    int Hcl = 0;
+    void *ycl = bn_take_cl_out(&Hcl);
     if (!bn_pair_ok(x_dt, a_dt)) { mi_record_error("mid_bn_apply_t", "unsupported storage types"); return -2; }
     hipStream_t st = (hipStream_t)s;
     mi_prof_begin(st, MI_FAM_BN, 0.0, (double)N * C * P * (dt_bytes(x_dt) + dt_bytes(a_dt) * (residual ? 2 : 1)));
-    const int rc = bn_fwd_apply(st, x, x_dt, gamma, beta, residual, means, vars, y, a_dt, nullptr, nullptr, N, C, P, eps, relu);
+    const int rc = bn_fwd_apply(st, x, x_dt, gamma, beta, residual, means, vars, y, a_dt, nullptr, nullptr, N, C, P, eps, relu, ycl, Hcl);
     mi_prof_end(st);
     return rc;
 }
@@ -644,6 +645,8 @@ int mid_bn_apply_t(mid_stream s, const void *x, int x_dt, const float *gamma, co
 int mid_bn_fwd_t(mid_stream s, float *ws, const mid_bn_parts *parts, const void *x, int x_dt, const float *gamma, const float *beta,
                  const void *residual, float *means, float *vars, void *y, int a_dt, float *xhat_out, float *norm_out, int N, int C,
                  int P, float eps, int relu) {
+    int Hcl = 0;
+    void *ycl = bn_take_cl_out(&Hcl);
     if (!bn_pair_ok(x_dt, a_dt)) { mi_record_error("mid_bn_fwd_t", "unsupported storage types"); return -2; }
     if ((xhat_out || norm_out) && !(x_dt == MID_F32 && a_dt == MID_F32)) { mi_record_error("mid_bn_fwd_t", "full-store tensors exist in fp32 only"); return -2; }
     hipStream_t st = (hipStream_t)s;
@@ -678,7 +681,7 @@ int mid_bn_fwd_t(mid_stream s, float *ws, const mid_bn_parts *parts, const void 
         hipLaunchKernelGGL(bn_sync_k3, dim3(mi_cdiv(C, 256)), dim3(256), 0, st, tmp + C, vars, C, iw);
         MI_LAUNCH_CHECK("bn_sync");
     }
-    const int rc = bn_fwd_apply(st, x, x_dt, gamma, beta, residual, means, vars, y, a_dt, xhat_out, norm_out, N, C, P, eps, relu);
+    const int rc = bn_fwd_apply(st, x, x_dt, gamma, beta, residual, means, vars, y, a_dt, xhat_out, norm_out, N, C, P, eps, relu, ycl, Hcl);
     mi_prof_end(st);
     return rc;
 }

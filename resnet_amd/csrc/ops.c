@@ -282,6 +282,16 @@ int mi_op_bn_fwd_t(const void *x, int x_dt, const float *gamma, const float *bet
     mid_free(ws);
     return rc;
 }
+/* BN + ReLU of a bf16 tensor with the output written twice, as forward_pass does in front of a stride-1 3x3: y (bf16 NCHW) and ycl =
+ * the same values as a zero-padded channel-last plane [N][H+2][H+2][C] (the caller zeroes ycl once: only the interior is written) */
+int mi_op_bn_fwd_cl_bf16(const void *x, const float *gamma, const float *beta, float *means, float *vars, void *y, void *ycl, int N, int C, int H,
+                         float eps) {
+    float *ws = (float *)mid_malloc(mid_bn_ws_floats(C) * sizeof(float));
+    mid_bn_set_cl_out(ycl, H);
+    int rc = finish(mid_bn_fwd_t(mi_global()->compute, ws, NULL, x, MID_BF16, gamma, beta, NULL, means, vars, y, MID_BF16, NULL, NULL, N, C, H * H, eps, 1));
+    mid_free(ws);
+    return rc;
+}
 int mi_op_bn_bwd_t(const void *x, int x_dt, const float *gamma, const float *beta, const float *means, const float *vars,
                    const void *dy, const void *mask_src, void *gated_out, int a_dt, void *dx, float *dgamma, float *dbeta, int N, int C,
                    int H, float eps, int mask_mode) {

@@ -223,6 +223,16 @@ class Ops:
         self._chk(self.L.mi_op_conv_wgrad_bf16_cl(dx.ptr, ddy.ptr, dw.ptr, N, Cc, H, K, stride), "conv_wgrad_bf16_cl")
         return dw.get()
 
+    def bn_fwd_cl_bf16(self, x, gamma, beta, eps):
+        """BN + ReLU written twice (bn_apply_cl_kernel): returns means, vars, y (NCHW) and the channel-last plane [N][H+2][H+2][C]"""
+        N, Cc, H, _ = x.shape
+        BF = B.MI_DTYPE_BF16
+        dx, dg, db = self.dev_t(x, BF), self.dev(gamma), self.dev(beta)
+        dm, dv, dy = self.dev(shape=(Cc,)), self.dev(shape=(Cc,)), self.new_t(x.shape, BF)
+        ycl = self.dev_t(np.zeros((N, H + 2, H + 2, Cc), np.float32), BF)   # zero halo
+        self._chk(self.L.mi_op_bn_fwd_cl_bf16(dx.ptr, dg.ptr, db.ptr, dm.ptr, dv.ptr, dy.ptr, ycl.ptr, N, Cc, H, eps), "bn_fwd_cl_bf16")
+        return dm.get(), dv.get(), self.get_t(dy, BF), self.get_t(ycl, BF)
+
     def conv1x1_fwd_bf16_cl(self, x, w):
         N, Cc, H, _ = x.shape
         K = w.shape[0]
