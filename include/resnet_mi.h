@@ -355,6 +355,7 @@ int mi_trainer_check_errors(Train_ResNet *t);
  * reference walks locations[] from the last to the first, :2952, so the highest offending index is the one it prints); -1 = none.
  * mi_trainer_set_nan_exit(t, 0): a report no longer ends the process (the reference's exit(1), :2899) but comes back through
  * mi_trainer_check_errors / mi_trainer_nan_location -- for tests. */
+int mi_trainer_stem_dtype(Train_ResNet *t); /* storage type of activations->init_conv_applied (the stem convolution's own output) and of its gradient: MI_DTYPE_BF16 in the bf16 mode with the matrix-core stem, else MI_DTYPE_F32 */
 int mi_trainer_nan_location(const Train_ResNet *t);
 void mi_trainer_set_nan_exit(Train_ResNet *t, int on);
 /* test aid: the device-side merge of cross-replica batch norm (mi_dp_enable_sync_bn) on R replicas held by ONE process -- the

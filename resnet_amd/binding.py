@@ -181,6 +181,7 @@ PROTOTYPES = {
     "mi_trainer_check_errors": (_i, [_T]),
     "mi_trainer_end_epoch": (None, [_T, _f, _f, _f]),
     "mi_trainer_nan_location": (_i, [_T]),
+    "mi_trainer_stem_dtype": (_i, [_T]),
     "mi_trainer_set_nan_exit": (None, [_T, _i]),
     "mi_debug_bn_merge": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp]),
     "mi_debug_dp_plan": (_i, [C.POINTER(Dims), _sz, _vp, _vp, _i]),

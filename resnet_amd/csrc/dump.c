@@ -103,7 +103,7 @@ static void dump_activations(int dump_id, Train_ResNet *t, Activations *a, int i
         write_dev(base, "fc_output.buffer", t->backprop_buffer->output_layer_deriv, (size_t)N * d->output);
     }
     if (imgs) {
-        write_img(base, "init_conv_applied.buffer", a->init_conv_applied, N, f, Hs, scratch); /* the stem's tensors are fp32 */
+        write_img_t(base, "init_conv_applied.buffer", a->init_conv_applied, N, f, Hs, scratch, adt == MID_BF16 && ctx->stem_bf16 ? MID_BF16 : MID_F32);
         if (!rc) write_img_t(base, "init_conv_activated.buffer", a->init_conv_activated, N, f, Hs, scratch, adt);
         write_img_t(base, "init_convblock_input.buffer", a->init_convblock_input, N, f, Hp, scratch, adt);
     }

@@ -117,8 +117,11 @@ __device__ __forceinline__ void st_stat_write(const StStat &a, float *__restrict
 }
 
 // ---- forward ----
+// YB: the output tensor is bf16 (the bf16 trainer: the stem's output is an activation tensor like any other convolution's; the statistics
+// still come from the fp32 accumulators), else fp32
+template <bool YB>
 __global__ void __launch_bounds__(256)
-st_fwd_kernel(const u16 *__restrict__ xp, const u16 *__restrict__ wf, float *__restrict__ y, const StArgs g, int ntiles, float *__restrict__ bn_part) {
+st_fwd_kernel(const u16 *__restrict__ xp, const u16 *__restrict__ wf, void *__restrict__ yv, const StArgs g, int ntiles, float *__restrict__ bn_part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char st_smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
@@ -186,12 +189,15 @@ st_fwd_kernel(const u16 *__restrict__ xp, const u16 *__restrict__ wf, float *__r
             }
         // read back with 8 lanes along a channel row (32 pixels = 128 bytes): 8 channels per wave instruction
         const int c4 = lane & 7, r0 = lane >> 3;
-        float *dst = y + ((size_t)n * ST_K) * g.P + p0 + 4 * c4;
+        const size_t doff = ((size_t)n * ST_K) * g.P + p0 + 4 * c4;
 #pragma unroll
         for (int ps = 0; ps < 8; ps++) {
             const int ch = ps * 8 + r0;
             const pf4 v = *(const pf4 *)(img + ch * PITCH + c4 * 16);
-            if (ST_ABL != 1 || v[0] == 1.2345f) *(pf4 *)(dst + (size_t)ch * g.P) = v;
+            if (ST_ABL != 1 || v[0] == 1.2345f) {
+                if (YB) *(u32x2 *)((u16 *)yv + doff + (size_t)ch * g.P) = u32x2{mi_pack_bf2(v[0], v[1]), mi_pack_bf2(v[2], v[3])};
+                else *(pf4 *)((float *)yv + doff + (size_t)ch * g.P) = v;
+            }
         }
     }
     if (bn_part) { st_stat_write(stat[0], bn_part, nw, gw, l31, kh); st_stat_write(stat[1], bn_part, nw, gw, 32 + l31, kh); }
@@ -200,8 +206,10 @@ st_fwd_kernel(const u16 *__restrict__ xp, const u16 *__restrict__ wf, float *__r
 // ---- weight gradient: per-wave partials [wave][64][160] ----
 // NS register sets of operands in a ring (see st32_wgrad_kernel below for why the loads are unconditional): a chunk's 10 MFMAs are
 // 320 cycles, so seven chunks of loads are kept in flight; one wave per SIMD.
+// DB: dY is a bf16 tensor (the bf16 trainer), else fp32 rounded to bf16 on the way in -- the same operand bits either way
+template <bool DB>
 __global__ void __launch_bounds__(256)
-st_wgrad_kernel(const u16 *__restrict__ xp, const float *__restrict__ dy, float *__restrict__ part, const StArgs g, int nchunks) {
+st_wgrad_kernel(const u16 *__restrict__ xp, const void *__restrict__ dyv, float *__restrict__ part, const StArgs g, int nchunks) {
     constexpr int NS = 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
@@ -225,7 +233,7 @@ st_wgrad_kernel(const u16 *__restrict__ xp, const float *__restrict__ dy, float 
     const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
     // a wave owns a CONTIGUOUS range of chunks: its 64 dY rows and its plane rows are sequential streams
     const int per = (nchunks + nw - 1) / nw, c_beg = gw * per, c_end = min(nchunks, (gw + 1) * per);
-    pf4 a[NS][2][2];
+    pf4 a[NS][2][DB ? 1 : 2];       // DB: 8 bf16 values = 16 bytes, kept as the raw bits in one pf4
     u32x4 b[NS][5];
     if (c_beg < c_end) {
         auto load = [&](int chunk, auto set_tag) {
@@ -234,11 +242,14 @@ st_wgrad_kernel(const u16 *__restrict__ xp, const float *__restrict__ dy, float 
             const uint32_t n = fd_div((uint32_t)chunk, g.fdTpi);
             const uint32_t p0 = ((uint32_t)chunk - n * g.fdTpi.d) * 16u;   // 16 consecutive pixels of one output row (Wo % 16 == 0)
             const uint32_t ho = fd_div(p0, g.fdWo), wo0 = p0 - ho * (uint32_t)g.Wo;
-            const float *da = dy + ((size_t)n * ST_K + l31) * g.P + p0 + 8 * kh;
+            const size_t da = ((size_t)n * ST_K + l31) * g.P + p0 + 8 * kh;
 #pragma unroll
             for (int i = 0; i < 2; i++) {
-                a[S][i][0] = *(const pf4 *)(da + (size_t)(32 * i) * g.P);
-                a[S][i][1] = *(const pf4 *)(da + (size_t)(32 * i) * g.P + 4);
+                if constexpr (DB) a[S][i][0] = *(const pf4 *)((const u16 *)dyv + da + (size_t)(32 * i) * g.P);
+                else {
+                    a[S][i][0] = *(const pf4 *)((const float *)dyv + da + (size_t)(32 * i) * g.P);
+                    a[S][i][DB ? 0 : 1] = *(const pf4 *)((const float *)dyv + da + (size_t)(32 * i) * g.P + 4);
+                }
             }
             const u16 *xb = xp + (size_t)n * g.img + (size_t)ho * g.pitch + wo0;
 #pragma unroll
@@ -249,9 +260,12 @@ st_wgrad_kernel(const u16 *__restrict__ xp, const float *__restrict__ dy, float 
             bf16x8 av[2];
 #pragma unroll
             for (int i = 0; i < 2; i++) {
-                const u32x4 pk = {mi_pack_bf2(a[S][i][0][0], a[S][i][0][1]), mi_pack_bf2(a[S][i][0][2], a[S][i][0][3]),
-                                  mi_pack_bf2(a[S][i][1][0], a[S][i][1][1]), mi_pack_bf2(a[S][i][1][2], a[S][i][1][3])};
-                av[i] = *(const bf16x8 *)&pk;
+                if constexpr (DB) av[i] = *(const bf16x8 *)&a[S][i][0];
+                else {
+                    const u32x4 pk = {mi_pack_bf2(a[S][i][0][0], a[S][i][0][1]), mi_pack_bf2(a[S][i][0][2], a[S][i][0][3]),
+                                      mi_pack_bf2(a[S][i][DB ? 0 : 1][0], a[S][i][DB ? 0 : 1][1]), mi_pack_bf2(a[S][i][DB ? 0 : 1][2], a[S][i][DB ? 0 : 1][3])};
+                    av[i] = *(const bf16x8 *)&pk;
+                }
             }
 #pragma unroll
             for (int i = 0; i < 2; i++)
@@ -498,8 +512,8 @@ size_t mid_stem_bf16_part_floats(int N, int H) {
     (void)N; (void)H;
     return (size_t)ST_WAVES * ST_K * ST_COLS + ST_K * ST_KRED; /* wave partials; the forward's bf16 weights sit behind them */
 }
-/* y (fp32) = conv7x7s2(bf16(x), bf16(w)); leaves the padded parity planes of x in xp for the weight gradient */
-int mid_stem_fwd_bf16(mid_stream s, const float *x, const float *w, float *y, void *xp, size_t xp_bytes, float *scratch, size_t scratch_floats,
+/* y (fp32, or bf16 with y_dt = MID_BF16) = conv7x7s2(bf16(x), bf16(w)); leaves the padded parity planes of x in xp for the weight gradient */
+int mid_stem_fwd_bf16(mid_stream s, const float *x, const float *w, void *y, int y_dt, void *xp, size_t xp_bytes, float *scratch, size_t scratch_floats,
                       int N, int H, mid_bn_parts *parts) {
     hipStream_t st = (hipStream_t)s;
     StArgs g; st_geometry(g, N, H);
@@ -514,7 +528,8 @@ int mid_stem_fwd_bf16(mid_stream s, const float *x, const float *w, float *y, vo
     g.fdTpi = make_fastdiv(g.P / 32);
     const int waves = st_waves(ntiles);
     float *bn_part = st_parts(parts, waves);
-    hipLaunchKernelGGL(st_fwd_kernel, dim3(waves / 4), dim3(256), 4 * 64 * (32 * 4 + 16), st, (const u16 *)xp, wf, y, g, ntiles, bn_part);
+    if (y_dt == MID_BF16) hipLaunchKernelGGL(st_fwd_kernel<true>, dim3(waves / 4), dim3(256), 4 * 64 * (32 * 4 + 16), st, (const u16 *)xp, wf, y, g, ntiles, bn_part);
+    else hipLaunchKernelGGL(st_fwd_kernel<false>, dim3(waves / 4), dim3(256), 4 * 64 * (32 * 4 + 16), st, (const u16 *)xp, wf, y, g, ntiles, bn_part);
     mi_prof_end(st);
     MI_LAUNCH_CHECK("st_fwd_kernel");
     return 0;
@@ -567,8 +582,8 @@ int mid_stem_wgrad_f32(mid_stream s, const void *xp, const float *dy, float *dw,
     MI_LAUNCH_CHECK("st32_wgrad_kernel");
     return 0;
 }
-/* dw (KCRS fp32) from the planes the forward left in xp and dy (fp32, rounded to bf16 on the way in) */
-int mid_stem_wgrad_bf16(mid_stream s, const void *xp, const float *dy, float *dw, float *scratch, size_t scratch_floats, int N, int H) {
+/* dw (KCRS fp32) from the planes the forward left in xp and dy (bf16, or fp32 rounded to bf16 on the way in: the same operand bits) */
+int mid_stem_wgrad_bf16(mid_stream s, const void *xp, const void *dy, int dy_dt, float *dw, float *scratch, size_t scratch_floats, int N, int H) {
     hipStream_t st = (hipStream_t)s;
     StArgs g; st_geometry(g, N, H);
     if (scratch_floats < mid_stem_bf16_part_floats(N, H)) { mi_record_error("mid_stem_wgrad_bf16", "workspace too small"); return -3; }
@@ -576,7 +591,8 @@ int mid_stem_wgrad_bf16(mid_stream s, const void *xp, const float *dy, float *dw
     g.fdTpi = make_fastdiv(g.P / 16);
     const int waves = st_waves(nchunks, ST_WAVES / 2); /* one wave per SIMD (register ring) */
     mi_prof_begin(st, MI_FAM_WGRAD, 2.0 * N * g.P * ST_K * 147.0, 4.0 * ((double)N * ST_K * g.P) + 2.0 * N * g.img);
-    hipLaunchKernelGGL(st_wgrad_kernel, dim3(waves / 4), dim3(256), 0, st, (const u16 *)xp, dy, scratch, g, nchunks);
+    if (dy_dt == MID_BF16) hipLaunchKernelGGL(st_wgrad_kernel<true>, dim3(waves / 4), dim3(256), 0, st, (const u16 *)xp, dy, scratch, g, nchunks);
+    else hipLaunchKernelGGL(st_wgrad_kernel<false>, dim3(waves / 4), dim3(256), 0, st, (const u16 *)xp, dy, scratch, g, nchunks);
     hipLaunchKernelGGL(st_wgrad_reduce_kernel, dim3((ST_K * 147 + 63) / 64), dim3(256), 0, st, scratch, dw, waves);
     mi_prof_end(st);
     MI_LAUNCH_CHECK("st_wgrad_kernel");

@@ -179,9 +179,9 @@ int mid_stem_wgrad_f32(mid_stream s, const void *xp, const float *dy, float *dw,
 int mid_stem_bf16_supported(int C, int H, int K, int k, int stride);
 size_t mid_stem_bf16_xp_bytes(int N, int H);
 size_t mid_stem_bf16_part_floats(int N, int H);
-int mid_stem_fwd_bf16(mid_stream s, const float *x, const float *w, float *y, void *xp, size_t xp_bytes, float *scratch, size_t scratch_floats,
+int mid_stem_fwd_bf16(mid_stream s, const float *x, const float *w, void *y, int y_dt, void *xp, size_t xp_bytes, float *scratch, size_t scratch_floats,
                       int N, int H, mid_bn_parts *parts); /* parts (optional): BN statistics partials of y, as mid_conv_fwd_stats leaves them */
-int mid_stem_wgrad_bf16(mid_stream s, const void *xp, const float *dy, float *dw, float *scratch, size_t scratch_floats, int N, int H);
+int mid_stem_wgrad_bf16(mid_stream s, const void *xp, const void *dy, int dy_dt, float *dw, float *scratch, size_t scratch_floats, int N, int H);
 int mid_f32_to_bf16(mid_stream s, const float *in, void *out, size_t n);
 int mid_bf16_to_f32(mid_stream s, const void *in, float *out, size_t n);
 

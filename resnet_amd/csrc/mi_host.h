@@ -81,6 +81,7 @@ typedef struct MiCtx {
      * fills fz_req before the unit whose dgrad should do it; the unit's dgrad moves it to fz_done (nparts > 0) for the next unit_bwd */
     mid_bn_bwd_parts fz_req, fz_done;
     void *bn_cl_out; int bn_cl_H; /* forward: the next unit's BN apply also writes this channel-last plane (stride-1 3x3 input), or NULL */
+    int stem_bf16;               /* bf16 mode: the stem convolution's output and its gradient are bf16 tensors too (RESNET_MI_BF16_STEM_TENSORS=f32: fp32 as in round 2) */
     int cl_wgrad2;               /* bf16: stride-2 weight gradients with both operands channel-last where the plane does not fill 64-pixel tiles (RESNET_MI_BF16_CL_WGRAD2=0: off) */
     int fz_bf16;                 /* bf16: which dgrads carry a BN' reduction (sites 1 | 2 | 4 as fz_f32; RESNET_MI_BF16_BNFUSE_SITES, default all) */
     int fz_req_valid, fz_ready, fz_enable, fz_f32; /* fz_f32: the fp32 dgrads do it too (RESNET_MI_F32_BNFUSE_BWD, default on) */

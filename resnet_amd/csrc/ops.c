@@ -206,7 +206,7 @@ int mi_op_stem_fwd_bf16(const float *x, const float *w, float *y, int N, int H) 
     const size_t xb = mid_stem_bf16_xp_bytes(N, H), sf = mid_stem_bf16_part_floats(N, H);
     void *xp = mi_malloc(xb);
     float *sc = (float *)mid_malloc(sf * sizeof(float));
-    int rc = (!xp || !sc) ? -3 : finish(mid_stem_fwd_bf16(mi_global()->compute, x, w, y, xp, xb, sc, sf, N, H, NULL));
+    int rc = (!xp || !sc) ? -3 : finish(mid_stem_fwd_bf16(mi_global()->compute, x, w, y, MID_F32, xp, xb, sc, sf, N, H, NULL));
     mid_free(sc);
     mi_free(xp);
     return rc;
@@ -217,8 +217,8 @@ int mi_op_stem_wgrad_bf16(const float *x, const float *w, const float *dy, float
     void *xp = mi_malloc(xb);
     float *sc = (float *)mid_malloc(sf * sizeof(float));
     float *y = (float *)mid_malloc((size_t)N * 64 * (H / 2) * (H / 2) * sizeof(float));
-    int rc = (!xp || !sc || !y) ? -3 : mid_stem_fwd_bf16(mi_global()->compute, x, w, y, xp, xb, sc, sf, N, H, NULL); /* leaves the padded planes in xp */
-    if (!rc) rc = mid_stem_wgrad_bf16(mi_global()->compute, xp, dy, dw, sc, sf, N, H);
+    int rc = (!xp || !sc || !y) ? -3 : mid_stem_fwd_bf16(mi_global()->compute, x, w, y, MID_F32, xp, xb, sc, sf, N, H, NULL); /* leaves the padded planes in xp */
+    if (!rc) rc = mid_stem_wgrad_bf16(mi_global()->compute, xp, dy, MID_F32, dw, sc, sf, N, H);
     rc = finish(rc);
     mid_free(y);
     mid_free(sc);

@@ -498,7 +498,7 @@ static void build_buffers(Train_ResNet *t) {
     if (c->policy == MI_STORE_FULL) add_full_store_extras(t);
     const int f = d->init_conv_filters, Hs = d->input / d->init_conv_stride;
     c->stem_dx = c->dtype == MID_BF16 ? falloc(c, (size_t)N * f * Hs * Hs) : NULL;
-    c->stem_xp = NULL; c->stem_scratch = NULL; c->stem_xp_bytes = 0; c->stem_scratch_floats = 0;
+    c->stem_xp = NULL; c->stem_scratch = NULL; c->stem_xp_bytes = 0; c->stem_scratch_floats = 0; c->stem_bf16 = 0;
     if (c->dtype == MID_F32 && mid_igemm_mode() > 0 && mid_stem_bf16_supported(3, d->input, f, d->init_kernel_dim, d->init_conv_stride) &&
         !(getenv("RESNET_MI_STEM_MFMA") && atoi(getenv("RESNET_MI_STEM_MFMA")) == 0)) {
         /* fp32 storage: the stem in exact fp32 on the matrix cores (kernels_stem_bf16.hip, st32_*) */
@@ -514,6 +514,9 @@ static void build_buffers(Train_ResNet *t) {
         c->stem_scratch_floats = mid_stem_bf16_part_floats(N, d->input);
         c->stem_xp = aalloc(c, (c->stem_xp_bytes + 1) / 2);                 /* (aalloc counts 2-byte elements in bf16 mode) */
         c->stem_scratch = falloc(c, c->stem_scratch_floats);
+        /* its output and that tensor's gradient are stored as bf16 like every other convolution's (they stay in their fp32-sized buffers):
+         * 822 MB tensors at N = 256 that the stem BN reads twice forward and three times backward */
+        c->stem_bf16 = !(getenv("RESNET_MI_BF16_STEM_TENSORS") && !strcmp(getenv("RESNET_MI_BF16_STEM_TENSORS"), "f32"));
     }
     float *pool[6];
     for (int i = 0; i < 6; i++) pool[i] = aalloc(c, maxe);
@@ -811,7 +814,7 @@ static void unit_fwd(Train_ResNet *t, const float *in, const float *w, const Bat
            "stem convolution forward (fp32 matrix cores)");
     } else if (stem && c->stem_scratch) {
         parts = &c->bn_parts; /* (the stem's tensors are fp32 here, but its statistics still come from the kernel's accumulators) */
-        ck(mid_stem_fwd_bf16(G.compute, in, w, conv_out, c->stem_xp, c->stem_xp_bytes, c->stem_scratch, c->stem_scratch_floats, N, H, parts),
+        ck(mid_stem_fwd_bf16(G.compute, in, w, conv_out, c->stem_bf16 ? MID_BF16 : MID_F32, c->stem_xp, c->stem_xp_bytes, c->stem_scratch, c->stem_scratch_floats, N, H, parts),
            "stem convolution forward (bf16 operands)");
     } else if (bf && k == 3 && stride == 1 && c->cur_cl && we && we->fwd) {
         /* the reduction BN wrote this input as a zero-padded channel-last plane beside its NCHW output: no re-layout pass */
@@ -827,7 +830,7 @@ static void unit_fwd(Train_ResNet *t, const float *in, const float *w, const Bat
     } else ck(mid_conv_fwd_stats(G.compute, &c->ws, in, w, conv_out, N, C, H, K, k, stride, parts), "convolution forward");
     c->ws.pre_fwd = NULL;
     if (c->bn_cl_out) { mid_bn_set_cl_out(bf ? c->bn_cl_out : NULL, c->bn_cl_H); c->bn_cl_out = NULL; }
-    ck(mid_bn_fwd_t(G.compute, c->bn_ws, parts, conv_out, bf ? MID_BF16 : MID_F32, bn->gamma, bn->beta, residual, cache->means, cache->vars,
+    ck(mid_bn_fwd_t(G.compute, c->bn_ws, parts, conv_out, (bf || (stem && c->stem_bf16)) ? MID_BF16 : MID_F32, bn->gamma, bn->beta, residual, cache->means, cache->vars,
                     act_out, c->dtype, cache->normalized_temp, cache->normalized, N, K, Ho * Ho, t->eps, relu), "batch norm forward");
 }
 
@@ -976,7 +979,7 @@ static void conv_wgrad_t(Train_ResNet *t, mid_stream st, const float *x, const f
     if (stem && c->stem_scratch && c->dtype == MID_F32)
         ck(mid_stem_wgrad_f32(st, c->stem_xp, dy, dw, c->stem_scratch, c->stem_scratch_floats, t->batch_size, H), "stem convolution wgrad (fp32 matrix cores)");
     else if (stem && c->stem_scratch) /* the forward pass left the batch as padded bf16 parity planes */
-        ck(mid_stem_wgrad_bf16(st, c->stem_xp, dy, dw, c->stem_scratch, c->stem_scratch_floats, t->batch_size, H), "stem convolution wgrad (bf16 operands)");
+        ck(mid_stem_wgrad_bf16(st, c->stem_xp, dy, c->stem_bf16 ? MID_BF16 : MID_F32, dw, c->stem_scratch, c->stem_scratch_floats, t->batch_size, H), "stem convolution wgrad (bf16 operands)");
     else if (c->dtype == MID_BF16 && !stem && k == 3 && c->cur_cl && c->cur_dye && c->cur_dye_valid && c->cl_wgrad2 &&
              mid_cl_wgrad2_supported(t->batch_size, C, H, K, stride) && (((H / stride) * (H / stride)) % 64 != 0 || !mid_cl_wgrad_supported(t->batch_size, C, H, K, stride)))
         /* both operands channel-last (the dY planes the dgrad has just made): planes that do not fill 64-pixel tiles (784, 196, 49 pixels:
@@ -996,7 +999,7 @@ static void unit_bwd(Train_ResNet *t, const float *in, const float *w, const Bat
                      int stride, int stem) {
     MiCtx *c = ctx_of(t);
     const int N = t->batch_size, Ho = H / stride;
-    const int x_dt = (c->dtype == MID_BF16 && !stem) ? MID_BF16 : MID_F32;
+    const int x_dt = (c->dtype == MID_BF16 && (!stem || c->stem_bf16)) ? MID_BF16 : MID_F32;
     /* BN' of this unit (HBM-bound) runs next to earlier units' weight gradients (FMA-bound, low-priority aux stream);
      * mask_mode 3: ReLU' of the block output fused in, and its product with the upstream gradient kept (gated_out) */
     if (c->fz_ready) { /* the dgrad that produced dy gated it and left the sums: merge, finalize, apply */
@@ -1276,6 +1279,10 @@ int mi_trainer_check_errors(Train_ResNet *t) {
 }
 /* the locations[] index the last NaN / Inf report named (-1: none); mi_trainer_set_nan_exit(t, 0) makes the report return through
  * mi_trainer_check_errors instead of exit(1) (tests) */
+/* storage type of the stem convolution's own output and of that tensor's gradient (MI_DTYPE_*): bf16 in the bf16 mode when the stem runs
+ * on the matrix cores, fp32 otherwise (fp32 mode; VALU stem; RESNET_MI_BF16_STEM_TENSORS=f32) */
+int mi_trainer_stem_dtype(Train_ResNet *t) { const MiCtx *c = ctx_of(t); return c->dtype == MID_BF16 && c->stem_bf16 ? MID_BF16 : MID_F32; }
+
 int mi_trainer_nan_location(const Train_ResNet *t) { return ((const MiCtx *)t->backend_ctx)->nan_location; }
 void mi_trainer_set_nan_exit(Train_ResNet *t, int on) {
     MiCtx *c = ctx_of(t);

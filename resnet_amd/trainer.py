@@ -172,6 +172,10 @@ class Trainer:
         n = self.batch * self.dims["output"]
         return np.ctypeslib.as_array(t.forward_buffer.contents.pred_cpu, shape=(n,)).reshape(self.batch, -1).copy()
 
+    def stem_dtype(self):
+        """storage type of the stem convolution's own output and its gradient (MI_DTYPE_*)"""
+        return self.L.mi_trainer_stem_dtype(self.t)
+
     def labels(self):
         return np.ctypeslib.as_array(self.c_batch.contents.correct_classes_cpu, shape=(self.batch,)).copy()
 
@@ -190,8 +194,9 @@ class Trainer:
         Hp = Hs // d["init_maxpool_stride"]
         if name == "input":
             return self._to_host(self.c_batch.contents.images, N * 3 * d["input"] ** 2).reshape(N, 3, d["input"], d["input"])
-        if name == "init_conv_applied":  # the stem convolution's tensors are fp32 in every storage type
-            return self._to_host(a.init_conv_applied, N * f * Hs * Hs).reshape(N, f, Hs, Hs)
+        if name == "init_conv_applied":  # the stem convolution's own output: bf16 in the bf16 mode with the matrix-core stem, else fp32
+            get = self._act_to_host if self.stem_dtype() == B.MI_DTYPE_BF16 else self._to_host
+            return get(a.init_conv_applied, N * f * Hs * Hs).reshape(N, f, Hs, Hs)
         if name == "init_conv_activated":
             return self._act_to_host(a.init_conv_activated, N * f * Hs * Hs).reshape(N, f, Hs, Hs)
         if name == "init_convblock_input":

@@ -383,7 +383,7 @@ def test_training_step_bf16_vs_fp32_oracle(oracle, cfg):
             assert abs(gl - ol) <= LOSS_ABS_BF16, (gl, ol)
             # float64 arithmetic, bf16 rounding at the product's storage points, the product's own gates: same parameters and batch
             # (the PRODUCT's current parameters: after the first update they differ from the oracle's by up to 2 lr per element)
-            emu = torch_ref.TorchNetBF16(dims, [tr.get("params", i) for i in range(net.n_locations)], eps=HYPER["eps"], gates=torch_ref.gates_of(tr, dims))
+            emu = torch_ref.TorchNetBF16(dims, [tr.get("params", i) for i in range(net.n_locations)], eps=HYPER["eps"], gates=torch_ref.gates_of(tr, dims), stem_bf16=tr.stem_dtype() == BF16)
             emu.forward(torch_ref.nhwc_to_nchw(im), lab)
             emu_grads = emu.backward()
             net.backward()
@@ -524,7 +524,7 @@ def test_resnet50_bf16_every_block_and_both_bn_backward_routes(oracle):
                 net.param(i)[:] = p
             net.set_batch(im, lab)
             net.forward()
-            emu = torch_ref.TorchNetBF16(dims, params, eps=HYPER["eps"])
+            emu = torch_ref.TorchNetBF16(dims, params, eps=HYPER["eps"], stem_bf16=tr.stem_dtype() == BF16)
             emu.forward(torch_ref.nhwc_to_nchw(im), lab)
             for b in range(dims["n_conv_blocks"]):
                 nm = "conv_blocks/%02d/output_activated" % b
@@ -562,7 +562,7 @@ def test_resnet50_bf16_every_block_and_both_bn_backward_routes(oracle):
     params = damped
 
     def shared_gate_model(tr, im, lab):
-        shared = torch_ref.TorchNetBF16(dims, params, eps=HYPER["eps"], gates=torch_ref.gates_of(tr, dims))
+        shared = torch_ref.TorchNetBF16(dims, params, eps=HYPER["eps"], gates=torch_ref.gates_of(tr, dims), stem_bf16=tr.stem_dtype() == BF16)
         shared.forward(torch_ref.nhwc_to_nchw(im), lab)
         out15 = rel_l2(tr.activation("conv_blocks/15/output_activated"), shared.acts["b15_out"].detach().numpy())
         print("  damped residual branches, batch 8: last block output, HIP vs the rounding model with the product's gates: %.2e" % out15)

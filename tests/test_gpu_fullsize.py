@@ -127,7 +127,7 @@ def test_fullsize_forward_properties(r50):
               "init_conv_applied": "batch_norms/init"}[name]
         m, v = tr.activation(bn + "/means"), tr.activation(bn + "/vars")
         rm, rv = x.mean(axis=(0, 2, 3)), x.var(axis=(0, 2, 3))  # biased variance, as resnet.cu:321
-        if dtype == F32 or name == "init_conv_applied":  # (the stem convolution's own output is an fp32 tensor in both storage types)
+        if dtype == F32 or (name == "init_conv_applied" and tr.stem_dtype() == F32):  # (the stem convolution's own output: Trainer.stem_dtype())
             assert np.allclose(m, rm, rtol=1e-5, atol=1e-6 * np.abs(rm).max()), name
             assert np.allclose(v, rv, rtol=2e-5), name
         else:

@@ -110,7 +110,8 @@ class TorchNet:
 # ---- bf16-storage emulation (BASELINE configs[4]): the same float64 model with every ACTIVATION tensor and every activation
 # gradient rounded to bf16 (round to nearest even) where the product stores it: convolution outputs of the bottleneck
 # blocks, BN(+ReLU) outputs, block outputs, and the gradients flowing back through the same tensors; bottleneck weights
-# are rounded when used (fp32 master copies).  The stem convolution's own output stays unrounded, like the product's.
+# are rounded when used (fp32 master copies).  The stem convolution's own output is rounded too when the product stores it as bf16
+# (stem_bf16: Trainer.stem_dtype() -- the matrix-core stem; the VALU stem of inputs that are not a multiple of 32 keeps fp32 tensors).
 # It is the yardstick for how far bf16 storage ALONE moves a gradient from the fp32 oracle's (tests/test_gpu_bf16.py): on
 # these small random-init nets a rounded pre-activation flips ~0.3 % of the ReLU gates per layer, which is ~5 % in rel-L2.
 def _rb(t):
@@ -133,9 +134,10 @@ class TorchNetBF16(TorchNet):
     positions).  With them the model takes those decisions instead of its own, so the two executions' gradients differ by
     rounding alone: a pre-activation within bf16 rounding of 0 no longer shows up as an O(1) difference of that element."""
 
-    def __init__(self, dims, params, eps=1e-7, dtype=torch.float64, gates=None):
+    def __init__(self, dims, params, eps=1e-7, dtype=torch.float64, gates=None, stem_bf16=False):
         super().__init__(dims, params, eps, dtype)
         self.gates = gates
+        self.stem_bf16 = stem_bf16
 
     def _relu(self, z, key):
         if self.gates is None:
@@ -146,10 +148,10 @@ class TorchNetBF16(TorchNet):
         w = self.p[i].view(K, C, k, k)
         stem = name == "stem"
         w = w + (_rb(w.detach()) - w.detach())  # rounded value, gradient to the fp32 master copy
-        if stem:  # the stem multiplies the bf16-rounded image (kernels_stem_bf16.hip); its output stays an fp32 tensor.  (Its weight
-            x = _rb(x)  # gradient also rounds dY on the way in: 2^-9 relative noise per element, averaged over 10^5..10^6 terms)
+        if stem:  # the stem multiplies the bf16-rounded image (kernels_stem_bf16.hip).  (Its weight gradient rounds dY on the way in when
+            x = _rb(x)  # that tensor is fp32: 2^-9 relative noise per element, averaged over 10^5..10^6 terms)
         y = F.conv2d(x, w, stride=stride, padding=k // 2)
-        if not stem:
+        if not stem or self.stem_bf16:
             y = _RoundBF16.apply(y)
         z = bn_train(y, self.p[i + 1], self.p[i + 2], self.eps)
         if residual is not None:

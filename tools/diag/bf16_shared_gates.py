@@ -15,7 +15,7 @@ for name, dims, batch in (("C4I", synth.C4I_DIMS, 4), ("C1S", synth.C1S_DIMS, 4)
         im, lab = synth.make_batch(dims, batch, step=step)
         tr.fill_host_batch(im, lab); tr.load_new_batch(); tr.forward()
         cur = [tr.get("params", i) for i in range(tr.n_locations)]
-        emu = torch_ref.TorchNetBF16(dims, cur, eps=1e-7, gates=torch_ref.gates_of(tr, dims))
+        emu = torch_ref.TorchNetBF16(dims, cur, eps=1e-7, gates=torch_ref.gates_of(tr, dims), stem_bf16=tr.stem_dtype() == 1)
         emu.forward(torch_ref.nhwc_to_nchw(im), lab); eg = emu.backward()
         tr.backward()
         rs = [rel_l2(tr.get("grads", i), eg[i].reshape(-1)) for i in range(tr.n_locations)]
