@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0
 FAMILIES_F32 = {0: "7x7 stem fwd (st32_pad + st32_fwd_kernel, fp32 MFMA)", 1: "7x7 stem wgrad (st32_wgrad_kernel, fp32 MFMA)",
                 2: "1x1 conv / FC GEMM (igemm_kernel<*,1,1,*> / gemm_mfma_kernel, fp32 MFMA)", 3: "batch norm fwd+bwd",
                 5: "3x3 conv fwd+dgrad+wgrad incl. the 3x3-s2 projections (igemm_kernel<*,3,*,*>, implicit GEMM on fp32 MFMA)"}
-FAMILIES_BF16 = {0: "7x7 stem fwd (st_pad + st_fwd_kernel, bf16 MFMA, fp32 output)", 1: "7x7 stem wgrad (st_wgrad_kernel, bf16 MFMA, fp32 dY)",
+FAMILIES_BF16 = {0: "7x7 stem fwd (st_pad + st_fwd_kernel, bf16 MFMA, bf16 output)", 1: "7x7 stem wgrad (st_wgrad_kernel, bf16 MFMA, bf16 dY)",
                  2: "1x1 conv (bgemm_kernel<*,1,1,*>, bf16 MFMA) + FC GEMM (fp32 MFMA)", 3: "batch norm fwd+bwd (bf16 tensors, fp32 math)",
                  5: "3x3 conv fwd+dgrad+wgrad incl. the 3x3-s2 projections (bgemm_kernel<*,3,*,*> on NCHW; the stride-2 layers on channel-last operands: cl_conv / cl_dgrad2 / cl_wgrad_kernel; implicit GEMM on bf16 MFMA)"}
 PMC_KEY = {0: "dconv", 1: "wgradC", 2: "gemm", 3: "bn", 5: "igemm3x3"}

@@ -520,7 +520,7 @@ int mid_stem_fwd_bf16(mid_stream s, const float *x, const float *w, void *y, int
     if (xp_bytes < mid_stem_bf16_xp_bytes(N, H) || scratch_floats < mid_stem_bf16_part_floats(N, H)) { mi_record_error("mid_stem_fwd_bf16", "workspace too small"); return -3; }
     const size_t pairs = (size_t)N * g.img / 2;
     size_t pb = (pairs + 255) / 256; if (pb > (1u << 20)) pb = 1u << 20;
-    mi_prof_begin(st, MI_FAM_DCONV, 2.0 * N * g.P * ST_K * 147.0, 4.0 * ((double)N * 3 * H * H + (double)N * ST_K * g.P));
+    mi_prof_begin(st, MI_FAM_DCONV, 2.0 * N * g.P * ST_K * 147.0, 4.0 * (double)N * 3 * H * H + (y_dt == MID_BF16 ? 2.0 : 4.0) * (double)N * ST_K * g.P);
     hipLaunchKernelGGL(st_pad_kernel, dim3((unsigned)pb), dim3(256), 0, st, x, (u16 *)xp, g, pairs);
     u16 *wf = (u16 *)(scratch + (size_t)ST_WAVES * ST_K * ST_COLS);
     hipLaunchKernelGGL(st_wt_kernel, dim3((ST_K * ST_KRED + 255) / 256), dim3(256), 0, st, w, wf);
@@ -590,7 +590,7 @@ int mid_stem_wgrad_bf16(mid_stream s, const void *xp, const void *dy, int dy_dt,
     const int nchunks = N * (g.P / 16);
     g.fdTpi = make_fastdiv(g.P / 16);
     const int waves = st_waves(nchunks, ST_WAVES / 2); /* one wave per SIMD (register ring) */
-    mi_prof_begin(st, MI_FAM_WGRAD, 2.0 * N * g.P * ST_K * 147.0, 4.0 * ((double)N * ST_K * g.P) + 2.0 * N * g.img);
+    mi_prof_begin(st, MI_FAM_WGRAD, 2.0 * N * g.P * ST_K * 147.0, (dy_dt == MID_BF16 ? 2.0 : 4.0) * ((double)N * ST_K * g.P) + 2.0 * N * g.img);
     if (dy_dt == MID_BF16) hipLaunchKernelGGL(st_wgrad_kernel<true>, dim3(waves / 4), dim3(256), 0, st, (const u16 *)xp, dy, scratch, g, nchunks);
     else hipLaunchKernelGGL(st_wgrad_kernel<false>, dim3(waves / 4), dim3(256), 0, st, (const u16 *)xp, dy, scratch, g, nchunks);
     hipLaunchKernelGGL(st_wgrad_reduce_kernel, dim3((ST_K * 147 + 63) / 64), dim3(256), 0, st, scratch, dw, waves);
