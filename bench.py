@@ -375,6 +375,11 @@ def main():
         sys.exit(launch_workers(args, argv))
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it, and it must be there before HIP starts
+    # stdout carries ONE JSON line and nothing else: gloo and RCCL print banners on fd 1 ("[Gloo] Rank 0 is connected ...", "RCCL version :
+    # ...").  Everything written to fd 1 from here on goes to stderr; the record is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     from resnet_amd import binding as B
     lib = B.load()
     if lib.mi_device_count() < 1:
@@ -450,7 +455,8 @@ def main():
             out["bf16"] = bf16_rec
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

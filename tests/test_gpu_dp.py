@@ -287,3 +287,19 @@ def test_sync_bn_merge_of_two_different_replicas_equals_the_whole_batch(oracle, 
 
 def nchw_(a):
     return np.ascontiguousarray(np.transpose(a, (0, 3, 1, 2)))
+
+
+@pytest.mark.gpu
+def test_bench_stdout_is_one_json_line_on_the_distributed_path():
+    """the driver reads ONE JSON line from rank 0's stdout: gloo and RCCL print banners on fd 1 ("[Gloo] Rank 0 is connected ...", "RCCL
+    version : ..."), which bench.py sends to stderr.  --force-dist runs the rendezvous + RCCL path with one rank."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["MASTER_PORT"] = "29617"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--dtype", "bf16", "--batch", "32", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-extra", "--no-prof"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, r.stdout[:2000]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["dtype"] == "bf16" and rec["value"] > 0
