@@ -402,7 +402,7 @@ int mi_op_conv_dgrad_bn_bwd_bf16(const float *w_kcrs, const void *dy, const void
  * and semantics as mi_op_conv_fwd_bf16 / mi_op_conv_dgrad_bf16 with k = 3; -2: shape not covered (channels % 64) */
 int mi_op_conv_fwd_bf16_cl(const void *x_bf16, const float *w_kcrs, void *y_bf16, int N, int C, int H, int K, int stride);
 int mi_op_conv_wgrad_bf16_cl(const void *x_bf16, const void *dy_bf16, float *dw_kcrs, int N, int C, int H, int K, int stride); /* C % 128, K % 128, plane % 4 */
-int mi_op_bn_fwd_cl_bf16(const void *x_bf16, const float *gamma, const float *beta, float *means, float *vars, void *y_bf16, void *y_cl, int N, int C, int H, float eps); /* BN + ReLU written twice: NCHW and as the zero-padded channel-last plane [N][H+2][H+2][C] (interior only; C % 64) */
+int mi_op_bn_fwd_cl_bf16(const void *x_bf16, const float *gamma, const float *beta, const void *residual_bf16, float *means, float *vars, void *y_bf16, void *y_cl, int N, int C, int H, float eps, int par); /* BN (+ residual) + ReLU written twice: NCHW and channel-last (par 0: one zero-padded plane [N][H+2][H+2][C]; par 1: the four parity planes of a stride-2 3x3; interior only; C % 64) */
 int mi_op_conv1x1_fwd_bf16_cl(const void *x_bf16, const float *w_kc, void *y_bf16, int N, int C, int H, int K); /* 1x1 forward on the input re-laid dense channel-last (one tap of the channel-last kernel); C, K % 64 */
 int mi_op_conv_wgrad_bf16_cl2(const void *x, const void *dy, float *dw, int N, int C, int H, int K, int stride); /* 3x3: BOTH operands as channel-last planes (stride 2: the input's parity planes and the dY planes of the stride-2 dgrad; stride 1: both with a halo of 1); C, K % 128, any plane size */
 int mi_op_conv_dgrad_bf16_cl(const float *w_kcrs, const void *dy_bf16, void *dx_bf16, int N, int C, int H, int K, int stride, int to_add); /* stride 2: C % 128, no to_add */

@@ -200,7 +200,7 @@ PROTOTYPES = {
     "mi_op_conv_wgrad_bf16_cl": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "mi_op_conv_wgrad_bf16_cl2": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "mi_op_conv1x1_fwd_bf16_cl": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),
-    "mi_op_bn_fwd_cl_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, C.c_float]),
+    "mi_op_bn_fwd_cl_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, C.c_float, _i]),
     "mi_op_conv_dgrad_bf16_cl": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     "mi_op_conv_dgrad_bn_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "mi_op_stem_fwd_f32": (_i, [_vp, _vp, _vp, _i, _i]),

@@ -230,7 +230,8 @@ typedef uint32_t bn_u32x4 __attribute__((ext_vector_type(4)));
 typedef bn_u32x4 __attribute__((aligned(2))) bn_u32x4_u2;
 __global__ void __launch_bounds__(256)
 bn_apply_cl_kernel(const bf16_t *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ means,
-                   const float *__restrict__ vars, bf16_t *__restrict__ y, bf16_t *__restrict__ ycl, int C, int P, int W, float eps, FastDiv fdW) {
+                   const float *__restrict__ vars, const bf16_t *__restrict__ residual, bf16_t *__restrict__ y, bf16_t *__restrict__ ycl, int C, int P, int W,
+                   float eps, FastDiv fdW, int par) {
     __shared__ __attribute__((aligned(16))) bf16_t tile[64 * 72];  // [pixel][64 channels], pitch 72
     const int c0 = blockIdx.x * 64, p0 = blockIdx.y * 64, n = blockIdx.z;
 #pragma unroll
@@ -240,17 +241,25 @@ bn_apply_cl_kernel(const bf16_t *__restrict__ x, const float *__restrict__ gamma
         const float mean = means[c], sd = sqrtf(vars[c] + eps), g = gamma[c], b = beta[c];
         const size_t e = ((size_t)n * C + c) * P + pp;
         const int nv = min(8, P - pp);             // elements of this piece that lie in the plane (<= 0: none)
-        float v[8];
+        float v[8], r[8];
         if (nv >= 8) {
             const bn_u32x4 t = *(const bn_u32x4_u2 *)(x + e);
 #pragma unroll
             for (int q = 0; q < 4; q++) { v[2 * q] = __uint_as_float(t[q] << 16); v[2 * q + 1] = __uint_as_float(t[q] & 0xffff0000u); }
+            if (residual) {
+                const bn_u32x4 t2 = *(const bn_u32x4_u2 *)(residual + e);
+#pragma unroll
+                for (int q = 0; q < 4; q++) { r[2 * q] = __uint_as_float(t2[q] << 16); r[2 * q + 1] = __uint_as_float(t2[q] & 0xffff0000u); }
+            }
         } else {
 #pragma unroll
-            for (int q = 0; q < 8; q++) v[q] = q < nv ? mi_bf2f(x[e + q]) : 0.f;
+            for (int q = 0; q < 8; q++) { v[q] = q < nv ? mi_bf2f(x[e + q]) : 0.f; r[q] = (residual && q < nv) ? mi_bf2f(residual[e + q]) : 0.f; }
         }
 #pragma unroll
-        for (int q = 0; q < 8; q++) v[q] = fmaxf(bn_y(bn_xhat(v[q], mean, sd), g, b), 0.f);
+        for (int q = 0; q < 8; q++) { // bn_apply_kernel's arithmetic: BN, (+ residual), ReLU
+            const float nvq = bn_y(bn_xhat(v[q], mean, sd), g, b);
+            v[q] = residual ? fmaxf(nvq + r[q], 0.f) : fmaxf(nvq, 0.f);
+        }
         const bn_u32x4 o = {mi_pack_bf2(v[0], v[1]), mi_pack_bf2(v[2], v[3]), mi_pack_bf2(v[4], v[5]), mi_pack_bf2(v[6], v[7])};
         if (nv >= 8) *(bn_u32x4_u2 *)(y + e) = o;
         else {
@@ -271,7 +280,11 @@ bn_apply_cl_kernel(const bf16_t *__restrict__ x, const float *__restrict__ gamma
         const int p = p0 + px;
         if (p < P) {
             const uint32_t yy = fd_div((uint32_t)p, fdW), xx = (uint32_t)p - yy * W;
-            *(bn_u32x4 *)(ycl + (((size_t)n * (H + 2) + yy + 1) * (W + 2) + xx + 1) * C + c0 + piece * 8) = *(const bn_u32x4 *)(tile + px * 72 + piece * 8);
+            // par: the four parity planes a stride-2 3x3 reads (plane 2 (y & 1) + (x & 1), row (y >> 1) + 1, column (x >> 1) + 1, Hp = H / 2 + 1)
+            const int Hp = H / 2 + 1;
+            const size_t o = par ? ((((size_t)n * 4 + 2 * (yy & 1) + (xx & 1)) * Hp + (yy >> 1) + 1) * Hp + (xx >> 1) + 1) * C
+                                 : (((size_t)n * (H + 2) + yy + 1) * (W + 2) + xx + 1) * C;
+            *(bn_u32x4 *)(ycl + o + c0 + piece * 8) = *(const bn_u32x4 *)(tile + px * 72 + piece * 8);
         }
     }
 }
@@ -580,15 +593,17 @@ size_t mid_bn_parts_floats(int N, int K, int Ho) { return (size_t)3 * (size_t)mi
 /* side output of the NEXT forward apply (one-shot: the caller sets it right before the call, the launcher consumes it): the activation
  * also as a zero-padded channel-last plane of H x H pixels (bn_apply_cl_kernel) */
 static struct { void *out; int H; } g_bn_cl = {nullptr, 0};
+/* H > 0: one plane with a halo of 1; H < 0: the four parity planes of a stride-2 3x3 over an |H| x |H| image */
 extern "C" void mid_bn_set_cl_out(void *ycl, int H) { g_bn_cl.out = ycl; g_bn_cl.H = H; }
 /* taken (and cleared) at the ENTRY of the public launchers, so that an early error return cannot leave it for some later layer */
 static void *bn_take_cl_out(int *H) { void *p = g_bn_cl.out; *H = g_bn_cl.H; g_bn_cl.out = nullptr; return p; }
 static int bn_fwd_apply(hipStream_t st, const void *x, int x_dt, const float *gamma, const float *beta, const void *residual,
                         const float *means, const float *vars, void *y, int a_dt, float *xhat_out, float *norm_out, int N, int C,
                         int P, float eps, int relu, void *ycl = nullptr, int Hcl = 0) {
-    if (ycl && x_dt == MID_BF16 && a_dt == MID_BF16 && !residual && relu && !xhat_out && !norm_out && C % 64 == 0 && Hcl * Hcl == P) {
-        hipLaunchKernelGGL(bn_apply_cl_kernel, dim3(C / 64, mi_cdiv(P, 64), N), dim3(256), 0, st, (const bf16_t *)x, gamma, beta, means, vars, (bf16_t *)y,
-                           (bf16_t *)ycl, C, P, Hcl, eps, make_fastdiv(Hcl));
+    const int Hab = Hcl < 0 ? -Hcl : Hcl;
+    if (ycl && x_dt == MID_BF16 && a_dt == MID_BF16 && (residual || relu) && !xhat_out && !norm_out && C % 64 == 0 && Hab * Hab == P && !(Hcl < 0 && (Hab & 1))) {
+        hipLaunchKernelGGL(bn_apply_cl_kernel, dim3(C / 64, mi_cdiv(P, 64), N), dim3(256), 0, st, (const bf16_t *)x, gamma, beta, means, vars,
+                           (const bf16_t *)residual, (bf16_t *)y, (bf16_t *)ycl, C, P, Hab, eps, make_fastdiv(Hab), Hcl < 0);
         MI_LAUNCH_CHECK("bn_apply_cl_kernel");
         return 0;
     }

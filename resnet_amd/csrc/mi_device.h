@@ -150,7 +150,7 @@ int mid_cl_dgrad(mid_stream s, const void *dyp, const void *a_tiles, void *dx, c
 /* weight gradient from dY (NCHW) and the forward's re-laid input: transposed LDS reads on the pixel-major operand */
 int mid_cl_wgrad_supported(int N, int C, int H, int K, int stride);
 size_t mid_cl_wgrad_part_floats(int N, int C, int H, int K, int stride);
-void mid_bn_set_cl_out(void *ycl, int H); /* one-shot: the next mid_bn_fwd_t / mid_bn_apply_t also writes its (bf16, ReLU) output as a zero-padded channel-last plane */
+void mid_bn_set_cl_out(void *ycl, int H); /* one-shot: the next mid_bn_fwd_t / mid_bn_apply_t also writes its (bf16; ReLU or + residual, ReLU) output channel-last: H > 0 one plane with a halo of 1, H < 0 the four parity planes of a stride-2 3x3 over |H| x |H| */
 int mid_cl_pw_supported(int N, int C, int H, int K);
 int mid_cl_relayout_dense(mid_stream s, const void *x, void *xp, int N, int C, int H);
 int mid_cl_pw_fwd(mid_stream s, const void *xc, const void *a_tiles, void *y, int N, int C, int H, int K, mid_bn_parts *parts);

@@ -80,6 +80,8 @@ typedef struct MiCtx {
     /* bf16: the reduction pass of a unit's BN' done by the dgrad that produces its dy (mid_conv_dgrad_bn_bf16).  backwards_pass
      * fills fz_req before the unit whose dgrad should do it; the unit's dgrad moves it to fz_done (nparts > 0) for the next unit_bwd */
     mid_bn_bwd_parts fz_req, fz_done;
+    int cl_pre;                  /* bf16: the stride-2 layers' parity planes are written by the producing BN apply too (RESNET_MI_BF16_CL_PRE=0: by a re-layout pass) */
+    int cur_cl_ready;            /* forward: cur_cl already holds this step's planes (written by the producer) */
     void *bn_cl_out; int bn_cl_H; /* forward: the next unit's BN apply also writes this channel-last plane (stride-1 3x3 input), or NULL */
     int stem_bf16;               /* bf16 mode: the stem convolution's output and its gradient are bf16 tensors too (RESNET_MI_BF16_STEM_TENSORS=f32: fp32 as in round 2) */
     int cl_wgrad2;               /* bf16: stride-2 weight gradients with both operands channel-last where the plane does not fill 64-pixel tiles (RESNET_MI_BF16_CL_WGRAD2=0: off) */

@@ -282,13 +282,15 @@ int mi_op_bn_fwd_t(const void *x, int x_dt, const float *gamma, const float *bet
     mid_free(ws);
     return rc;
 }
-/* BN + ReLU of a bf16 tensor with the output written twice, as forward_pass does in front of a stride-1 3x3: y (bf16 NCHW) and ycl =
- * the same values as a zero-padded channel-last plane [N][H+2][H+2][C] (the caller zeroes ycl once: only the interior is written) */
-int mi_op_bn_fwd_cl_bf16(const void *x, const float *gamma, const float *beta, float *means, float *vars, void *y, void *ycl, int N, int C, int H,
-                         float eps) {
+/* BN (+ residual) + ReLU of a bf16 tensor with the output written twice, as forward_pass does in front of a 3x3: y (bf16 NCHW) and ycl =
+ * the same values channel-last -- par = 0: one zero-padded plane [N][H+2][H+2][C] (stride-1 3x3); par = 1: the four parity planes
+ * [N][2x2][H/2+1][H/2+1][C] of a stride-2 3x3 (the caller zeroes ycl once: only the interior is written) */
+int mi_op_bn_fwd_cl_bf16(const void *x, const float *gamma, const float *beta, const void *residual, float *means, float *vars, void *y, void *ycl,
+                         int N, int C, int H, float eps, int par) {
     float *ws = (float *)mid_malloc(mid_bn_ws_floats(C) * sizeof(float));
-    mid_bn_set_cl_out(ycl, H);
-    int rc = finish(mid_bn_fwd_t(mi_global()->compute, ws, NULL, x, MID_BF16, gamma, beta, NULL, means, vars, y, MID_BF16, NULL, NULL, N, C, H * H, eps, 1));
+    mid_bn_set_cl_out(ycl, par ? -H : H);
+    int rc = finish(mid_bn_fwd_t(mi_global()->compute, ws, NULL, x, MID_BF16, gamma, beta, residual, means, vars, y, MID_BF16, NULL, NULL, N, C, H * H, eps,
+                                 residual ? 0 : 1));
     mid_free(ws);
     return rc;
 }

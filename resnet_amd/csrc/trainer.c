@@ -565,6 +565,7 @@ Train_ResNet *init_trainer(ResNet *model, Batch *cur_batch, int batch_size, floa
      * bf16 kernel's row-major drain) and pays for it wherever the separate reduction pass was only 2 tensors; site 4 replaces a
      * 4-tensor pass and breaks even, so it is the default */
     c->fz_bf16 = getenv("RESNET_MI_BF16_BNFUSE_SITES") ? atoi(getenv("RESNET_MI_BF16_BNFUSE_SITES")) : 7;
+    c->cl_pre = !(getenv("RESNET_MI_BF16_CL_PRE") && atoi(getenv("RESNET_MI_BF16_CL_PRE")) == 0);
     c->cl_wgrad2 = !(getenv("RESNET_MI_BF16_CL_WGRAD2") && atoi(getenv("RESNET_MI_BF16_CL_WGRAD2")) == 0);
     c->fz_f32 = mid_igemm_mode() >= 2 ? (getenv("RESNET_MI_F32_BNFUSE_BWD") ? atoi(getenv("RESNET_MI_F32_BNFUSE_BWD")) : 4) : 0;
     c->overlap_wgrad = getenv("RESNET_MI_OVERLAP") ? atoi(getenv("RESNET_MI_OVERLAP")) : 1;
@@ -797,7 +798,7 @@ void mi_trainer_poll_errors(Train_ResNet *t) {
  * stem: the 7x7 convolution keeps fp32 input / output in every storage type; only its BN output is an activation tensor */
 /* c->cur_par: parity copy of the NEXT stride-2 convolution's input (set by the caller); c->cur_par_valid: where the forward pass
  * records whether it really wrote the planes (it does only on the 16-byte staging route), read back by the weight gradient */
-static void set_cur_par(MiCtx *c, void *buf, size_t bytes, int *valid) { c->cur_par = buf; c->cur_par_bytes = bytes; c->cur_par_valid = valid; c->cur_dye = NULL; c->cur_cl = NULL; c->cur_dye_valid = 0; }
+static void set_cur_par(MiCtx *c, void *buf, size_t bytes, int *valid) { c->cur_par = buf; c->cur_par_bytes = bytes; c->cur_par_valid = valid; c->cur_dye = NULL; c->cur_cl = NULL; c->cur_dye_valid = 0; c->cur_cl_ready = 0; }
 static void unit_fwd(Train_ResNet *t, const float *in, const float *w, const BatchNorm *bn, Cache_BatchNorm *cache,
                      float *conv_out, float *act_out, const float *residual, int C, int H, int K, int k, int stride,
                      int relu, int stem) {
@@ -821,7 +822,7 @@ static void unit_fwd(Train_ResNet *t, const float *in, const float *w, const Bat
         ck(mid_cl_fwd(G.compute, c->cur_cl, we->fwd, conv_out, N, C, H, K, 1, parts), "convolution forward (bf16, channel-last)");
     } else if (bf && k == 3 && stride == 2 && c->cur_cl && we && we->fwd) {
         /* channel-last route: the input re-laid once as four zero-padded parity planes, which the weight gradient reads again */
-        ck(mid_cl_relayout(G.compute, in, c->cur_cl, N, C, H, 1), "input re-layout (channel-last parity planes)");
+        if (!c->cur_cl_ready) ck(mid_cl_relayout(G.compute, in, c->cur_cl, N, C, H, 1), "input re-layout (channel-last parity planes)");
         ck(mid_cl_fwd(G.compute, c->cur_cl, we->fwd, conv_out, N, C, H, K, 2, parts), "convolution forward (bf16, channel-last)");
         if (c->cur_par_valid) *c->cur_par_valid = 0;
     } else if (bf) {
@@ -858,27 +859,37 @@ void forward_pass(Train_ResNet *t) {
     ck(mid_maxpool_fwd_t(G.compute, a->init_conv_activated, a->init_convblock_input, c->dtype, a->max_inds, N, f, Hs, d->init_maxpool_dim,
                          d->init_maxpool_stride), "max-pool forward");
     const float *bin = a->init_convblock_input;
+    int pr_ready = 0; /* the producing BN apply of the block before has already written this block's projection planes */
     for (int i = 0; i < d->n_conv_blocks; i++) {
         const ConvBlock *b = p->conv_blocks[i];
         Activation_ConvBlock *k = a->activation_conv_blocks[i];
         const int H = b->incoming_spatial_dim, Ho = H / b->stride;
+        int sp_ready = 0;
         if (c->par && c->par[i].cl_s1) { c->bn_cl_out = c->par[i].cl_s1; c->bn_cl_H = H; }
+        else if (c->par && c->cl_pre && b->stride == 2 && c->par[i].cl_spatial && !(H & 1)) { c->bn_cl_out = c->par[i].cl_spatial; c->bn_cl_H = -H; sp_ready = 1; }
         unit_fwd(t, bin, b->depth_reduction, b->norm_depth_reduction, k->norm_post_reduced, k->post_reduced,
                  k->post_reduced_activated, NULL, b->incoming_filters, H, b->reduced_depth, 1, 1, 1, 0);
         if (c->par) set_cur_par(c, c->par[i].spatial, c->par[i].spatial_bytes, &c->par[i].spatial_valid); else set_cur_par(c, NULL, 0, NULL);
         c->cur_cl = c->par ? (b->stride == 2 ? c->par[i].cl_spatial : c->par[i].cl_s1) : NULL;
+        c->cur_cl_ready = sp_ready;
         unit_fwd(t, k->post_reduced_activated, b->spatial, b->norm_spatial, k->norm_post_spatial, k->post_spatial,
                  k->post_spatial_activated, NULL, b->reduced_depth, H, b->reduced_depth, 3, b->stride, 1, 0);
         const float *res = bin;
         if (b->projection) { /* resnet.cu:1685-1704 */
             if (c->par) set_cur_par(c, c->par[i].proj, c->par[i].proj_bytes, &c->par[i].proj_valid); else set_cur_par(c, NULL, 0, NULL);
             c->cur_cl = c->par ? c->par[i].cl_proj : NULL;
+            c->cur_cl_ready = pr_ready;
             unit_fwd(t, bin, b->projection, b->norm_projection, k->norm_post_projection, k->transformed_residual,
                      k->post_projection_norm_vals, NULL, b->incoming_filters, H, b->expanded_depth, b->stride == 2 ? 3 : 1,
                      b->stride, 0, 0);
             res = k->post_projection_norm_vals;
         }
+        pr_ready = 0;
         if (!c->full_store) { /* BN(expanded) + addVec + doActivation in one kernel (:1670, :1717, :1723) */
+            if (c->par && c->cl_pre && i + 1 < d->n_conv_blocks && p->conv_blocks[i + 1]->stride == 2 && p->conv_blocks[i + 1]->projection &&
+                c->par[i + 1].cl_proj && !(Ho & 1)) { /* this block's output is the next block's 3x3 stride-2 projection input */
+                c->bn_cl_out = c->par[i + 1].cl_proj; c->bn_cl_H = -Ho; pr_ready = 1;
+            }
             unit_fwd(t, k->post_spatial_activated, b->depth_expansion, b->norm_expansion, k->norm_post_expanded,
                      k->post_expanded, k->output_activated, res, b->reduced_depth, Ho, b->expanded_depth, 1, 1, 0, 0);
         } else {

@@ -223,14 +223,18 @@ class Ops:
         self._chk(self.L.mi_op_conv_wgrad_bf16_cl(dx.ptr, ddy.ptr, dw.ptr, N, Cc, H, K, stride), "conv_wgrad_bf16_cl")
         return dw.get()
 
-    def bn_fwd_cl_bf16(self, x, gamma, beta, eps):
-        """BN + ReLU written twice (bn_apply_cl_kernel): returns means, vars, y (NCHW) and the channel-last plane [N][H+2][H+2][C]"""
+    def bn_fwd_cl_bf16(self, x, gamma, beta, eps, residual=None, par=False):
+        """BN (+ residual) + ReLU written twice (bn_apply_cl_kernel): returns means, vars, y (NCHW) and the channel-last copy -- one plane
+        [N][H+2][H+2][C], or (par) the four parity planes [N][4][H/2+1][H/2+1][C]"""
         N, Cc, H, _ = x.shape
         BF = B.MI_DTYPE_BF16
         dx, dg, db = self.dev_t(x, BF), self.dev(gamma), self.dev(beta)
+        dr = self.dev_t(residual, BF) if residual is not None else None
         dm, dv, dy = self.dev(shape=(Cc,)), self.dev(shape=(Cc,)), self.new_t(x.shape, BF)
-        ycl = self.dev_t(np.zeros((N, H + 2, H + 2, Cc), np.float32), BF)   # zero halo
-        self._chk(self.L.mi_op_bn_fwd_cl_bf16(dx.ptr, dg.ptr, db.ptr, dm.ptr, dv.ptr, dy.ptr, ycl.ptr, N, Cc, H, eps), "bn_fwd_cl_bf16")
+        shp = (N, 4, H // 2 + 1, H // 2 + 1, Cc) if par else (N, H + 2, H + 2, Cc)
+        ycl = self.dev_t(np.zeros(shp, np.float32), BF)   # zero halo
+        self._chk(self.L.mi_op_bn_fwd_cl_bf16(dx.ptr, dg.ptr, db.ptr, dr.ptr if dr else None, dm.ptr, dv.ptr, dy.ptr, ycl.ptr, N, Cc, H, eps, int(par)),
+                  "bn_fwd_cl_bf16")
         return dm.get(), dv.get(), self.get_t(dy, BF), self.get_t(ycl, BF)
 
     def conv1x1_fwd_bf16_cl(self, x, w):

@@ -697,18 +697,31 @@ def test_conv1x1_fwd_bf16_on_dense_channel_last_input(ops, oracle, shape):
 
 
 @pytest.mark.parametrize("C,H,N", [(64, 56, 2), (128, 28, 3), (256, 14, 3), (512, 7, 5), (64, 8, 4), (128, 5, 3)])
-def test_bn_relu_written_twice_nchw_and_channel_last(ops, C, H, N):
-    """bn_apply_cl_kernel (what forward_pass runs in front of a stride-1 3x3): the NCHW output is bit for bit the plain kernel's, the
-    channel-last plane holds the same values at [n][y+1][x+1][c] and its halo is untouched (zero); planes of 49 and 25 pixels end in
-    partial 8-pixel pieces and partial 64-pixel tiles"""
+@pytest.mark.parametrize("form", ["plane", "parity", "parity+residual", "plane+residual"])
+def test_bn_relu_written_twice_nchw_and_channel_last(ops, C, H, N, form):
+    """bn_apply_cl_kernel (what forward_pass runs in front of a 3x3): the NCHW output is bit for bit the plain kernel's; the channel-last copy
+    holds the same values -- one plane at [n][y+1][x+1][c] (stride-1 3x3), or four parity planes at [n][2 (y&1) + (x&1)][y/2+1][x/2+1][c]
+    (stride-2 3x3; with the residual form this is a block output feeding the next block's projection) -- and its halo is untouched (zero);
+    planes of 49 and 25 pixels end in partial 8-pixel pieces and partial 64-pixel tiles"""
+    par, res = form.startswith("parity"), form.endswith("residual")
+    if par and H % 2:
+        pytest.skip("parity planes need an even plane")
     eps = 1e-7
     x = bf16_round(rand((N, H, H, C), 3, 2.0) + 0.5)
+    r = bf16_round(rand((N, H, H, C), 6)) if res else None
     gamma = (1 + 0.2 * rand((C,), 4)).astype(np.float32)
     beta = (0.3 * rand((C,), 5)).astype(np.float32)
-    m0, v0, y0 = ops.bn_fwd_t(nchw(x), gamma, beta, eps, 1, BF16, BF16)
-    m1, v1, y1, ycl = ops.bn_fwd_cl_bf16(nchw(x), gamma, beta, eps)
+    m0, v0, y0 = ops.bn_fwd_t(nchw(x), gamma, beta, eps, 0 if res else 1, BF16, BF16, residual=nchw(r) if res else None)
+    m1, v1, y1, ycl = ops.bn_fwd_cl_bf16(nchw(x), gamma, beta, eps, residual=nchw(r) if res else None, par=par)
     assert np.array_equal(m0, m1) and np.array_equal(v0, v1)
     assert np.array_equal(y0, y1)
-    assert np.array_equal(ycl[:, 1:-1, 1:-1, :], nhwc(y1))
-    halo = ycl.copy(); halo[:, 1:-1, 1:-1, :] = 0
+    yh = nhwc(y1)
+    if par:
+        for pr in (0, 1):
+            for pc in (0, 1):
+                assert np.array_equal(ycl[:, 2 * pr + pc, 1:, 1:, :], yh[:, pr::2, pc::2, :])
+        halo = ycl.copy(); halo[:, :, 1:, 1:, :] = 0
+    else:
+        assert np.array_equal(ycl[:, 1:-1, 1:-1, :], yh)
+        halo = ycl.copy(); halo[:, 1:-1, 1:-1, :] = 0
     assert not halo.any()
