@@ -11,7 +11,7 @@
 //     base(n, oh, ow) + D(r, s),      D = ((q(r, s) Hp + (r > 0)) Wp + (s > 0)) C,   q = 2 ((r + 1) & 1) + ((s + 1) & 1)
 // -- one per-thread base per tile, one wave-uniform constant per tap, no masks, and the reduction index contiguous: exactly the MFMA
 // operand.  Both operand tiles ([128 rows][64 reduction elements] = rows of 128 bytes) go global -> LDS by LDS-DMA
-// (global_load_lds_dwordx4: no staging registers, no transposes, no ds_write instructions), XOR-swizzled through the SOURCE address
+// (buffer_load_dwordx4 ... lds: no staging registers, no transposes, no ds_write instructions), XOR-swizzled through the SOURCE address
 // (the DMA writes lane-linear) so that the ds_read_b128 fragment reads are conflict-free; two LDS buffers, the DMA of k-step i + 1 in
 // flight under the MFMAs of k-step i, one barrier per k-step.  Product pixel-major (pixels = accumulator rows) as in the NCHW kernel:
 // a lane ends with 4 consecutive pixels of one channel per accumulator quad -- lane-local BN statistics, and NCHW stores of whole
@@ -57,6 +57,17 @@ __device__ __forceinline__ float cl_bf2f(u16 v) { return __uint_as_float((uint32
 // row, so the key changes every second row -- the 16 lanes of a ds_read_b128 group (16 consecutive rows, one chunk) then cover all 16
 // slots of the two-row bank period
 __device__ __forceinline__ int cl_key(int row) { return (row >> 1) & 7; }
+// One 16-byte piece per lane, global -> LDS, by BUFFER addressing (buffer_load_dwordx4 ... offen lds): the lane's part of the address is one
+// 32-bit VGPR, the wave-uniform part one SGPR -- against the flat form (global_load_lds: a 64-bit address pair per lane, built with vector
+// adds for every piece) the eight DMA instructions of a k-step cost 565 instead of 876 cycles of a wave's issue time.  A lane whose offset
+// is past num_records gets ZEROS written to LDS (tools/ubench/buf_lds_oob.hip): CL_OOB is how a piece beyond a plane asks for zeros.
+#define CL_OOB 0xfffffff0u
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t cl_rsrc(const void *base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void cl_dma16(const __amdgpu_buffer_rsrc_t r, unsigned char *lds, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds, 16, (int)voff, (int)soff, 0, 0);
+}
 
 // x [N][C][H][W] bf16 -> channel-last, zero-padded (interior only: the halo is zeroed once, when the buffer is made).
 //   par = 0: one plane   Xc[n][y + yoff][x + xoff][c], Hp x Wp  (3x3 stride 1: yoff = xoff = 1, Hp = H + 2; dY of a stride-2 dgrad:
@@ -99,6 +110,14 @@ cl_relayout64_kernel(const u16 *__restrict__ x, u16 *__restrict__ xp, int C, int
 // WM: waves along M.  2: workgroup tile 128 (M) x 128 (pixels), waves 2 x 2; 1: 64 x 256, waves 1 x 4 (64-channel layers).  Wave tile 64 x 64.
 // NBUF: operand buffers (2: the DMA of k-step i + 1 runs under the MFMAs of k-step i, one barrier per k-step; 1: half the LDS, two
 // barriers per k-step, the overlap comes from the other workgroups of the CU)
+#ifdef CL_STAMP /* diagnostic build only (tools/variant.sh stamp "-DCL_STAMP" kernels_cl_bf16.hip; tools/diag/cl_stamps.py): where wave 0 of a workgroup spends its cycles */
+__device__ unsigned long long cl_stamps[8 * 16384];
+#define CL_NOW() __builtin_amdgcn_s_memtime()
+#define CL_ACC(var, t_from, t_to) do { (var) += (t_to) - (t_from); } while (0)
+#else
+#define CL_NOW() 0ull
+#define CL_ACC(var, t_from, t_to) do { } while (0)
+#endif
 template <int WM, int NBUF>
 __global__ void __launch_bounds__(256)
 cl_conv_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ In, u16 *__restrict__ Out, const ClArgs g) {
@@ -148,18 +167,17 @@ cl_conv_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ In, u16 *__r
     const int cpt = g.Cin / 64;                    // k-steps per tap
     const int ntiles = g.ntaps * cpt;
     int ld_t = 0, ld_c = 0;
+    // the per-thread part of a piece's address is a CONSTANT (aoff / boff), the k-step's part one SGPR: no vector arithmetic per piece
+    const __amdgpu_buffer_rsrc_t rA = cl_rsrc(Aop, 0xffffff00u), rB = cl_rsrc(In, 0xffffff00u);   // (every offset is in range: no bound needed)
     auto issue = [&](const int buf) {
-        const unsigned char *fa = (const unsigned char *)(Aop + ((size_t)(g.tap_w[ld_t] * cpt + ld_c) * g.M + m0) * 64);
-        const unsigned char *fb = (const unsigned char *)In + g.tap_delta[ld_t] + (uint32_t)(ld_c * 128);
+        const uint32_t sa = (uint32_t)(((g.tap_w[ld_t] * cpt + ld_c) * g.M + m0) * 128);
+        const uint32_t sb = g.tap_delta[ld_t] + (uint32_t)(ld_c * 128);
         unsigned char *la = cl_smem + buf * BUF + wave * 1024, *lb = cl_smem + buf * BUF + ABYTES + wave * 1024;
 #pragma unroll
         for (int u = 0; u < NAU; u++)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(fa + aoff[u]),
-                                             (__attribute__((address_space(3))) void *)(la + u * 4096), 16, 0, 0);
+            cl_dma16(rA, la + u * 4096, aoff[u], sa);
 #pragma unroll
-        for (int u = 0; u < NBU; u++)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(fb + boff[u]),
-                                             (__attribute__((address_space(3))) void *)(lb + u * 4096), 16, 0, 0);
+        for (int u = 0; u < NBU; u++) cl_dma16(rB, lb + u * 4096, boff[u], sb);
         // taps fastest: the nine k-steps of one 64-channel chunk read the same 128-byte lines of neighbouring pixels back to back, so the
         // re-reads hit in L2 (channel chunks fastest streamed BN x Cin x 2 bytes per workgroup between two uses of a line: 16 MB per XCD
         // at 1024 channels, four times its L2, and every tap went back to memory)
@@ -188,13 +206,20 @@ cl_conv_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ In, u16 *__r
         }
     };
 
+    [[maybe_unused]] unsigned long long st_begin = CL_NOW(), st_wait = 0, st_bar = 0, st_issue = 0, st_comp = 0;
     if constexpr (NBUF == 2) {
         issue(0);
         for (int it = 0; it < ntiles; it++) {
+            [[maybe_unused]] const unsigned long long t0 = CL_NOW();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this thread's pieces of tile `it` have landed ...
+            [[maybe_unused]] const unsigned long long t1 = CL_NOW();
             __syncthreads();   // ... and so have everyone's; everyone is done with the other buffer
+            [[maybe_unused]] const unsigned long long t2 = CL_NOW();
             if (it + 1 < ntiles) issue((it + 1) & 1);
+            [[maybe_unused]] const unsigned long long t3 = CL_NOW();
             compute(it & 1);
+            [[maybe_unused]] const unsigned long long t4 = CL_NOW();
+            CL_ACC(st_wait, t0, t1); CL_ACC(st_bar, t1, t2); CL_ACC(st_issue, t2, t3); CL_ACC(st_comp, t3, t4);
         }
     } else {
         for (int it = 0; it < ntiles; it++) {
@@ -206,6 +231,12 @@ cl_conv_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ In, u16 *__r
         }
     }
     __syncthreads();       // the epilogue re-uses the operand buffers
+#ifdef CL_STAMP
+    if (threadIdx.x == 0 && blockIdx.x < 16384) { // (the epilogue's own time = the launch's tail; not stamped)
+        unsigned long long *o = cl_stamps + (size_t)blockIdx.x * 8;
+        o[0] = st_begin; o[1] = CL_NOW(); o[2] = st_wait; o[3] = st_bar; o[4] = st_issue; o[5] = st_comp; o[6] = (unsigned long long)ntiles;
+    }
+#endif
 
     // ---- epilogue: accumulator (i, j): rows = the 32 pixels of column block j, row (r & 3) + 8 (r >> 2) + 4 (lane >> 5);
     // column = channel m0 + wm 64 + i 32 + (lane & 31) ----
@@ -391,23 +422,20 @@ cl_dgrad2_kernel(const u16 *__restrict__ Aop, const u16 *__restrict__ In, u16 *_
     const int cpt = g.K / 64;
     const int nt0 = nrt * cpt, ntiles = 3 * nrt * cpt; // k-steps of column parity 0 / in all
     int ld_i = 0, ld_c = 0;                        // tap index in the list (0 .. 3 nrt - 1), channel chunk
+    const __amdgpu_buffer_rsrc_t rA = cl_rsrc(Aop, 0xffffff00u), rB = cl_rsrc(In, 0xffffff00u);
     auto issue = [&](const int buf) {
         // tap ld_i: [0, nrt): pw = 0, row tap ld_i; [nrt, 3 nrt): pw = 1, row tap (ld_i - nrt) >> 1, column tap (ld_i - nrt) & 1
         const int pw1 = ld_i >= nrt;
         const int rt = pw1 ? (ld_i - nrt) >> 1 : ld_i, ctp = pw1 ? (ld_i - nrt) & 1 : 0;
         const int r = ph ? 2 * rt : 1, dh = ph ? 1 - rt : 0;
         const int sx = pw1 ? 2 * ctp : 1, dw = pw1 ? 1 - ctp : 0;
-        const unsigned char *fa = (const unsigned char *)(Aop + ((size_t)((3 * r + sx) * cpt + ld_c) * g.C + m0) * 64);
-        const unsigned char *fb = (const unsigned char *)In + (uint32_t)((dh * g.Wp + dw) * g.K + ld_c * 64) * 2u;
+        const uint32_t sa = (uint32_t)((((3 * r + sx) * cpt + ld_c) * g.C + m0) * 128);
+        const uint32_t sb = (uint32_t)((dh * g.Wp + dw) * g.K + ld_c * 64) * 2u;
         unsigned char *la = cl_smem + buf * BUF + wave * 1024, *lb = cl_smem + buf * BUF + ABYTES + wave * 1024;
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(fa + aoff[u]),
-                                             (__attribute__((address_space(3))) void *)(la + u * 4096), 16, 0, 0);
+        for (int u = 0; u < 4; u++) cl_dma16(rA, la + u * 4096, aoff[u], sa);
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(fb + boff[u]),
-                                             (__attribute__((address_space(3))) void *)(lb + u * 4096), 16, 0, 0);
+        for (int u = 0; u < 4; u++) cl_dma16(rB, lb + u * 4096, boff[u], sb);
         // taps fastest within a column parity (see cl_conv_kernel)
         if (ld_i < nrt) { if (++ld_i == nrt) { ld_i = 0; if (++ld_c == cpt) { ld_c = 0; ld_i = nrt; } } }
         else if (++ld_i == 3 * nrt) { ld_i = nrt; ld_c++; }
@@ -513,7 +541,7 @@ struct ClWgArgs {
     uint32_t tap_delta[9];
     FastDiv fdGW, fdPt, fdM, fdT, fd9;
     uint32_t tiles, total8;         // output tiles (with taps); (tiles * splits) rounded down to a multiple of 8
-    const u16 *zero;                // >= 256 zero bytes
+    uint32_t a_bytes, b_bytes;      // num_records of the two buffer descriptors (a piece past a plane is given an offset beyond them: zeros)
 };
 __device__ __forceinline__ int cl_keyb(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 constexpr int CLW_KPX = 64;                        // pixels per reduction step
@@ -579,22 +607,15 @@ cl_wgrad_kernel(const u16 *__restrict__ dY, const u16 *__restrict__ Xc, float *_
         bx[u] = xx;
     }
     const int tin0 = ld_p0 >> 6;
+    const __amdgpu_buffer_rsrc_t rA = cl_rsrc(dY, g.a_bytes), rB = cl_rsrc(Xc, g.b_bytes);
     auto issue = [&](const int buf) {
-        const unsigned char *fa = (const unsigned char *)dY + ((size_t)ld_n * g.K * g.P + ld_p0) * 2;        // wave-uniform
-        const unsigned char *fb = (const unsigned char *)Xc + (size_t)ld_n * g.img_rows * rowb;                // wave-uniform
+        const uint32_t sa = (uint32_t)(((size_t)ld_n * g.K * g.P + ld_p0) * 2);   // wave-uniform (tensors < 2^32 bytes: mid_cl_supported)
+        const uint32_t sb = ld_n * (uint32_t)g.img_rows * rowb;
         unsigned char *la = cl_smem + buf * BUF + wave * 1024, *lb = cl_smem + buf * BUF + ABYTES + wave * 1024;
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const unsigned char *src = ld_p0 < alim[u] ? fa + aoff[u] : (const unsigned char *)g.zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(la + u * 4096), 16, 0, 0);
-        }
+        for (int u = 0; u < 4; u++) cl_dma16(rA, la + u * 4096, ld_p0 < alim[u] ? aoff[u] : CL_OOB, sa);           // beyond the plane: zeros
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const unsigned char *src = ld_p0 + brow + 16 * u < g.P ? fb + boff[u] : (const unsigned char *)g.zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(lb + u * 4096), 16, 0, 0);
-        }
+        for (int u = 0; u < 4; u++) cl_dma16(rB, lb + u * 4096, ld_p0 + brow + 16 * u < g.P ? boff[u] : CL_OOB, sb);
         // the next tile: 64 pixels on, or pixel 0 of the next image
         ld_r++;
         ld_p0 += 64;
@@ -704,7 +725,7 @@ struct ClWg2Args {
     uint32_t tap_delta[9];
     FastDiv fdGW, fdP, fdM, fdT, fd9;
     uint32_t tiles, total8;
-    const u16 *zero;
+    uint32_t a_bytes, b_bytes;      // num_records of the two buffer descriptors
 };
 __global__ void __launch_bounds__(256, 2)
 cl_wgrad2_kernel(const u16 *__restrict__ dYc, const u16 *__restrict__ Xc, float *__restrict__ part, const ClWg2Args g) {
@@ -746,17 +767,16 @@ cl_wgrad2_kernel(const u16 *__restrict__ dYc, const u16 *__restrict__ Xc, float 
         lanec[u] = (uint32_t)((bchunk ^ cl_keyb(row)) * 16);
     }
     int ld_j0 = r_beg * 64;
+    const __amdgpu_buffer_rsrc_t rA = cl_rsrc(dYc, g.a_bytes), rB = cl_rsrc(Xc, g.b_bytes);
     auto issue = [&](const int buf) {
         unsigned char *la = cl_smem + buf * BUF + wave * 1024, *lb = la + ABYTES;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const bool ok = ld_j0 + brow + 16 * u < g.R;
-            const unsigned char *sa = (const unsigned char *)dYc + (rn[u] * g.a_imgb + ry[u] * g.a_rowb + rx[u] * acolb + g.a_off + (uint32_t)m0 * 2u + lanec[u]);
-            const unsigned char *sb = (const unsigned char *)Xc + (rn[u] * imgb + ry[u] * rowb + rx[u] * colb + tdelta + lanec[u]);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ok ? sa : (const unsigned char *)g.zero),
-                                             (__attribute__((address_space(3))) void *)(la + u * 4096), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ok ? sb : (const unsigned char *)g.zero),
-                                             (__attribute__((address_space(3))) void *)(lb + u * 4096), 16, 0, 0);
+            const uint32_t va = rn[u] * g.a_imgb + ry[u] * g.a_rowb + rx[u] * acolb + g.a_off + (uint32_t)m0 * 2u + lanec[u];
+            const uint32_t vb = rn[u] * imgb + ry[u] * rowb + rx[u] * colb + tdelta + lanec[u];
+            cl_dma16(rA, la + u * 4096, ok ? va : CL_OOB, 0u);   // rows past the end of the list: zeros
+            cl_dma16(rB, lb + u * 4096, ok ? vb : CL_OOB, 0u);
         }
         ld_j0 += 64;
 #pragma unroll
@@ -826,7 +846,7 @@ struct PwWgArgs {
     int mtiles;                     // K / 128
     FastDiv fdPt, fdM, fdT;
     uint32_t tiles, total8;         // output tiles; (tiles * splits) rounded down to a multiple of 8
-    const u16 *zero;                // >= 256 zero bytes
+    uint32_t a_bytes, b_bytes;      // num_records of the two buffer descriptors
 };
 __global__ void __launch_bounds__(256, 2)
 pw_wgrad_kernel(const u16 *__restrict__ dY, const u16 *__restrict__ X, float *__restrict__ part, const PwWgArgs g) {
@@ -869,21 +889,18 @@ pw_wgrad_kernel(const u16 *__restrict__ dY, const u16 *__restrict__ X, float *__
     uint32_t ld_n = fd_div((uint32_t)r_beg, g.fdPt);
     int ld_p0 = (r_beg - (int)ld_n * g.ptiles) * 64;
     const int tin0 = ld_p0 >> 6;
+    const __amdgpu_buffer_rsrc_t rA = cl_rsrc(dY, g.a_bytes), rB = cl_rsrc(X, g.b_bytes);
     auto issue = [&](const int buf) {
-        const unsigned char *fa = (const unsigned char *)dY + ((size_t)ld_n * g.K * g.P + ld_p0) * 2;        // wave-uniform
-        const unsigned char *fb = (const unsigned char *)X + ((size_t)ld_n * g.C * g.P + ld_p0) * 2;
-        unsigned char *la = cl_smem + buf * BUF + wave * 1024, *lb = la + ABYTES;
+        const uint32_t sa = (uint32_t)((size_t)ld_n * g.K * g.P * 2), sb = (uint32_t)((size_t)ld_n * g.C * g.P * 2);   // wave-uniform: the image
+        const uint32_t pb = (uint32_t)ld_p0 * 2u;  // the tile's first pixel goes into the LANE offset: the bound check sees only that part, and
+        unsigned char *la = cl_smem + buf * BUF + wave * 1024, *lb = la + ABYTES;   // "8 bytes early" must not take it below zero
         const int left = g.P - ld_p0;             // pixels of the plane from this tile's first one on
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             // whole chunk inside the plane: as it lies; the 4-pixel end chunk: 4 pixels (8 bytes) early; beyond the plane: zeros
             const int room = left - scx[u];
-            const unsigned char *sa = room >= 8 ? fa + aoff[u] : room > 0 ? fa + aoff[u] - 8 : (const unsigned char *)g.zero;
-            const unsigned char *sb = room >= 8 ? fb + boff[u] : room > 0 ? fb + boff[u] - 8 : (const unsigned char *)g.zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sa,
-                                             (__attribute__((address_space(3))) void *)(la + u * 4096), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sb,
-                                             (__attribute__((address_space(3))) void *)(lb + u * 4096), 16, 0, 0);
+            cl_dma16(rA, la + u * 4096, room >= 8 ? aoff[u] + pb : room > 0 ? aoff[u] + pb - 8u : CL_OOB, sa);
+            cl_dma16(rB, lb + u * 4096, room >= 8 ? boff[u] + pb : room > 0 ? boff[u] + pb - 8u : CL_OOB, sb);
         }
         ld_r++;
         ld_p0 += 64;
@@ -987,6 +1004,16 @@ static int cl_launch(hipStream_t st, const u16 *A, const u16 *In, u16 *Out, ClAr
 }
 
 extern "C" {
+/* diagnostic (-DCL_STAMP builds): the per-workgroup stamps of the last cl_conv_kernel launches; -1 in a normal build */
+int mi_debug_cl_stamps(unsigned long long *dst, int nblocks) {
+#ifdef CL_STAMP
+    if (nblocks > 16384) nblocks = 16384;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(cl_stamps), sizeof(unsigned long long) * 8 * (size_t)nblocks) == hipSuccess ? 0 : -1;
+#else
+    (void)dst; (void)nblocks;
+    return -1;
+#endif
+}
 /* shapes the channel-last kernels cover: 3x3, stride 1 or 2, channel counts a multiple of 64 (op 0 forward, 1 dgrad: stride 1 only) */
 int mid_cl_supported(int op, int N, int C, int H, int K, int stride) {
     if (stride != 1 && stride != 2) return 0;
@@ -1056,15 +1083,6 @@ int mid_cl_dgrad2(mid_stream s, const void *dyp, const void *a_tiles, void *dx, 
     MI_LAUNCH_CHECK("cl_dgrad2_kernel");
     return 0;
 }
-static void *g_cl_zero = nullptr;
-/* 512 zero bytes that pieces beyond a plane are loaded from; made once, and complete before the first launch on ANY stream */
-static int cl_zero_page(const char *who) {
-    if (g_cl_zero) return 0;
-    void *p = nullptr;
-    if (hipMalloc(&p, 512) != hipSuccess || hipMemset(p, 0, 512) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { mi_record_error(who, "zero page"); return -1; }
-    g_cl_zero = p;
-    return 0;
-}
 static int cl_wgrad_splits(int N, int C, int K, int P) {
     const long tiles = (long)(K / 128) * (C / 128) * 9, rt = (long)N * ((P + CLW_KPX - 1) / CLW_KPX);
     int best = 1;
@@ -1092,7 +1110,6 @@ size_t mid_cl_wgrad_part_floats(int N, int C, int H, int K, int stride) {
 int mid_cl_wgrad(mid_stream s, const void *xp, const void *dy, float *dw, float *part, size_t part_floats, int N, int C, int H, int K, int stride) {
     hipStream_t st = (hipStream_t)s;
     if (!mid_cl_wgrad_supported(N, C, H, K, stride)) { mi_record_error("mid_cl_wgrad", "shape not covered"); return -2; }
-    if (cl_zero_page("mid_cl_wgrad")) return -1;
     ClWgArgs g = {};
     g.K = K; g.C = C; g.GW = H / stride; g.P = g.GW * g.GW;
     if (stride == 2) {
@@ -1114,7 +1131,7 @@ int mid_cl_wgrad(mid_stream s, const void *xp, const void *dy, float *dw, float 
     g.ctiles = C / 128; g.mtiles = K / 128;
     g.fdGW = make_fastdiv(g.GW); g.fdPt = make_fastdiv(g.ptiles); g.fdM = make_fastdiv(g.mtiles); g.fdT = make_fastdiv(g.mtiles * g.ctiles * 9); g.fd9 = make_fastdiv(9);
     g.tiles = (uint32_t)(g.mtiles * g.ctiles * 9); g.total8 = (uint32_t)(g.mtiles * g.ctiles * 9 * used) & ~7u;
-    g.zero = (const u16 *)g_cl_zero;
+    g.a_bytes = (uint32_t)((size_t)N * K * g.P * 2); g.b_bytes = (uint32_t)mid_cl_operand_bytes(0, N, C, H, K, stride);
     static int attr_set = 0;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)cl_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess) { mi_record_error("cl_wgrad_kernel", "cannot raise the dynamic LDS limit"); return -1; }
@@ -1154,7 +1171,6 @@ size_t mid_cl_wgrad2_part_floats(int N, int C, int H, int K, int stride) { retur
 int mid_cl_wgrad2(mid_stream s, const void *xp, const void *dyp, float *dw, float *part, size_t part_floats, int N, int C, int H, int K, int stride) {
     hipStream_t st = (hipStream_t)s;
     if (!mid_cl_wgrad2_supported(N, C, H, K, stride)) { mi_record_error("mid_cl_wgrad2", "shape not covered"); return -2; }
-    if (cl_zero_page("mid_cl_wgrad2")) return -1;
     ClWg2Args g = {};
     g.K = K; g.C = C; g.GH = H / stride; g.GW = H / stride; g.R = N * g.GH * g.GW;
     if (stride == 2) {
@@ -1179,7 +1195,7 @@ int mid_cl_wgrad2(mid_stream s, const void *xp, const void *dyp, float *dw, floa
     g.ctiles = C / 128; g.mtiles = K / 128;
     g.fdGW = make_fastdiv(g.GW); g.fdP = make_fastdiv(g.GH * g.GW); g.fdM = make_fastdiv(g.mtiles); g.fdT = make_fastdiv(g.mtiles * g.ctiles * 9); g.fd9 = make_fastdiv(9);
     g.tiles = (uint32_t)(g.mtiles * g.ctiles * 9); g.total8 = (uint32_t)(g.mtiles * g.ctiles * 9 * used) & ~7u;
-    g.zero = (const u16 *)g_cl_zero;
+    g.a_bytes = (uint32_t)((size_t)N * g.a_imgb); g.b_bytes = (uint32_t)mid_cl_operand_bytes(0, N, C, H, K, stride);
     static int attr_set = 0;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)cl_wgrad2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess) { mi_record_error("cl_wgrad2_kernel", "cannot raise the dynamic LDS limit"); return -1; }
@@ -1217,7 +1233,6 @@ size_t mid_pw_wgrad_part_floats(int N, int C, int H, int K) { return (size_t)pw_
 int mid_pw_wgrad(mid_stream s, const void *x, const void *dy, float *dw, float *part, size_t part_floats, int N, int C, int H, int K) {
     hipStream_t st = (hipStream_t)s;
     if (!mid_pw_wgrad_supported(N, C, H, K)) { mi_record_error("mid_pw_wgrad", "shape not covered"); return -2; }
-    if (cl_zero_page("mid_pw_wgrad")) return -1;
     PwWgArgs g = {};
     g.K = K; g.C = C; g.P = H * H;
     g.ptiles = (g.P + 63) / 64; g.rtiles = N * g.ptiles;
@@ -1229,7 +1244,7 @@ int mid_pw_wgrad(mid_stream s, const void *x, const void *dy, float *dw, float *
     const int tiles = g.mtiles * (C / 128);
     g.fdPt = make_fastdiv(g.ptiles); g.fdM = make_fastdiv(g.mtiles); g.fdT = make_fastdiv(tiles);
     g.tiles = (uint32_t)tiles; g.total8 = (uint32_t)(tiles * used) & ~7u;
-    g.zero = (const u16 *)g_cl_zero;
+    g.a_bytes = (uint32_t)((size_t)N * K * g.P * 2); g.b_bytes = (uint32_t)((size_t)N * C * g.P * 2);
     static int attr_set = 0;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)pw_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess) { mi_record_error("pw_wgrad_kernel", "cannot raise the dynamic LDS limit"); return -1; }
