@@ -807,6 +807,62 @@ igemm_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw
     for (int t = 0; t < T; t++) dw[i * T + t] = s[t];
 }
 
+// The same sum for the launches the one-thread-per-output form leaves the chip idle on (K C / 256 workgroups: 64 for a 64 x 256 layer
+// with 100+ splits to walk): G threads per output, each adds a CONTIGUOUS group of splits in ascending order, the G sums are then added
+// in ascending group order -- a fixed tree, so still deterministic (not the same bits as the flat order).
+template <int T, int G>
+__global__ void __launch_bounds__(256)
+igemm_wgrad_reduce_g_kernel(const float *__restrict__ part, float *__restrict__ dw, long KC, int splits) {
+    constexpr int OPB = 256 / G;                   // outputs per workgroup: OPB consecutive floats of a partial plane per group
+    __shared__ float sh[G][OPB][T];
+    const int o = threadIdx.x % OPB, gq = threadIdx.x / OPB;
+    const long i = (long)blockIdx.x * OPB + o;
+    const int chunk = (splits + G - 1) / G, z0 = gq * chunk, z1 = min(splits, z0 + chunk);
+    float s[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) s[t] = 0.f;
+    if (i < KC) {
+        constexpr int U = T == 1 ? 8 : 2;
+        int z = z0;
+        for (; z + U <= z1; z += U) {
+            float v[U][T];
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int t = 0; t < T; t++) v[u][t] = part[((long)(z + u) * T + t) * KC + i];
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int t = 0; t < T; t++) s[t] += v[u][t];
+        }
+        for (; z < z1; z++)
+#pragma unroll
+            for (int t = 0; t < T; t++) s[t] += part[((long)z * T + t) * KC + i];
+    }
+#pragma unroll
+    for (int t = 0; t < T; t++) sh[gq][o][t] = s[t];
+    __syncthreads();
+    if (gq == 0 && i < KC) {
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            float r = sh[0][o][t];
+            for (int q = 1; q < G; q++) r += sh[q][o][t];
+            dw[i * T + t] = r;
+        }
+    }
+}
+static void igemm_wgrad_reduce_launch(hipStream_t st, const float *part, float *dw, long KC, int k, int splits) {
+    // groups of splits per output when one thread per output would leave most CUs without a workgroup
+    const bool grouped = splits >= 16 && mi_cdiv(KC, 256) < 1024;
+    if (k == 1) {
+        if (grouped) hipLaunchKernelGGL((igemm_wgrad_reduce_g_kernel<1, 8>), dim3(mi_cdiv(KC, 32)), dim3(256), 0, st, part, dw, KC, splits);
+        else hipLaunchKernelGGL(igemm_wgrad_reduce_kernel<1>, dim3(mi_cdiv(KC, 256)), dim3(256), 0, st, part, dw, KC, splits);
+    } else {
+        if (grouped) hipLaunchKernelGGL((igemm_wgrad_reduce_g_kernel<9, 8>), dim3(mi_cdiv(KC, 32)), dim3(256), 0, st, part, dw, KC, splits);
+        else hipLaunchKernelGGL(igemm_wgrad_reduce_kernel<9>, dim3(mi_cdiv(KC, 256)), dim3(256), 0, st, part, dw, KC, splits);
+    }
+}
+
 // dW[k][c] = sum_z part[z][c][k] (1x1, transposed product)
 __global__ void __launch_bounds__(256)
 igemm_wgrad_reduce_t_kernel(const float *__restrict__ part, float *__restrict__ dw, int K, int C, int splits) {
@@ -1116,8 +1172,7 @@ int mi_igemm_wgrad(hipStream_t st, mid_workspace *ws, const float *x, const floa
     if (rc) return rc;
     MI_LAUNCH_CHECK("igemm_kernel<wgrad>");
     const long KC = (long)K * C;
-    if (k == 1) hipLaunchKernelGGL(igemm_wgrad_reduce_kernel<1>, dim3(mi_cdiv(KC, 256)), dim3(256), 0, st, ws->part, dw, KC, used);
-    else hipLaunchKernelGGL(igemm_wgrad_reduce_kernel<9>, dim3(mi_cdiv(KC, 256)), dim3(256), 0, st, ws->part, dw, KC, used);
+    igemm_wgrad_reduce_launch(st, ws->part, dw, KC, k, used);
     MI_LAUNCH_CHECK("igemm_wgrad_reduce_kernel");
     return 0;
 }
@@ -1125,8 +1180,7 @@ int mi_igemm_wgrad(hipStream_t st, mid_workspace *ws, const float *x, const floa
 // second stage of a weight gradient whose partials are [split][t][k][c] (also used by the bf16 kernel)
 int mi_igemm_wgrad_reduce(hipStream_t st, const float *part, float *dw, int K, int C, int k, int splits) {
     const long KC = (long)K * C;
-    if (k == 1) hipLaunchKernelGGL(igemm_wgrad_reduce_kernel<1>, dim3(mi_cdiv(KC, 256)), dim3(256), 0, st, part, dw, KC, splits);
-    else hipLaunchKernelGGL(igemm_wgrad_reduce_kernel<9>, dim3(mi_cdiv(KC, 256)), dim3(256), 0, st, part, dw, KC, splits);
+    igemm_wgrad_reduce_launch(st, part, dw, KC, k, splits);
     MI_LAUNCH_CHECK("igemm_wgrad_reduce_kernel");
     return 0;
 }
