@@ -853,7 +853,9 @@ igemm_wgrad_reduce_g_kernel(const float *__restrict__ part, float *__restrict__ 
 }
 static void igemm_wgrad_reduce_launch(hipStream_t st, const float *part, float *dw, long KC, int k, int splits) {
     // groups of splits per output when one thread per output would leave most CUs without a workgroup
-    const bool grouped = splits >= 16 && mi_cdiv(KC, 256) < 1024;
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("RESNET_MI_WGRAD_REDUCE_G"); on = e ? atoi(e) : 1; }
+    const bool grouped = on && splits >= 16 && mi_cdiv(KC, 256) < 1024;
     if (k == 1) {
         if (grouped) hipLaunchKernelGGL((igemm_wgrad_reduce_g_kernel<1, 8>), dim3(mi_cdiv(KC, 32)), dim3(256), 0, st, part, dw, KC, splits);
         else hipLaunchKernelGGL(igemm_wgrad_reduce_kernel<1>, dim3(mi_cdiv(KC, 256)), dim3(256), 0, st, part, dw, KC, splits);
